@@ -1,0 +1,25 @@
+"""Definition of the golden cases shared by gen_golden.py (reference side, build container
+only) and the tests (oracle side / HIP side).  Inputs are regenerated from seeds
+(onepose_plus_plus_amd/synthetic.py); only reference OUTPUTS are stored in the .npz files."""
+
+# end-to-end forward cases: name -> (hw, n_points, thr, weight_seed, input_seed, fine_enabled)
+E2E_CASES = {
+    "e2e_128x128_n300_thr0": ((128, 128), 300, 0.0, 0, 1, True),
+    "e2e_64x96_n100_thr01": ((64, 96), 100, 0.1, 0, 1, True),
+    "e2e_96x64_n77_thr0": ((96, 64), 77, 0.0, 7, 11, True),           # ragged N, H != W
+    "e2e_128x128_n300_nomatch": ((128, 128), 300, 0.95, 0, 1, True),   # M == 0 branch
+    "e2e_512x512_n2000_thr0": ((512, 512), 2000, 0.0, 0, 1, True),     # BASELINE config 1
+    "e2e_512x512_n5000_coarse": ((512, 512), 5000, 0.0, 0, 1, False),  # BASELINE config 2
+}
+
+# planted coarse matcher: name -> (n_points, hw_c, n_planted, noise, seed, thr)
+MATCHER_CASES = {
+    "matcher_n5000_p3000": (5000, (64, 64), 3000, 0.1, 3, 0.1),
+    "matcher_n700_p300": (700, (16, 24), 300, 0.1, 4, 0.1),
+}
+
+# fine stage: name -> (n_points, hw_i, m, seed)
+FINE_CASES = {
+    "fine_m500": (5000, (512, 512), 500, 5),
+    "fine_m1": (100, (64, 96), 1, 6),
+}
