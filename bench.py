@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Throughput bench of the 2D-3D matching forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): one object, 512x512 query image x 5000-point cloud,
+coarse-match only (`fine_matching.enable=False`), B=1 per forward, synthetic image/bank and
+seeded random weights (no datasets or checkpoints are available offline).  A step is one
+`OnePosePlus_model(data)` forward through the HIP path with image and descriptor banks already
+resident in HBM.  With N GPUs every rank owns a different synthetic object (per-object sharding,
+SURVEY.md §8e): weights are broadcast once from rank 0 over RCCL, then there is no collective in
+the data path ("scaling": "weak").  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N=1 only):
+  roofline     - HIP-event timing (events recorded on the launch stream by libopp_hip.so) of
+                 every launch of the dominant kernel symbol, the 128x128-tile implicit-GEMM
+                 conv, during the timed steps; algorithmic FLOPs use unpadded channel counts.
+  cpu_baseline - the CPU oracle (oracle/onepose_oracle.py, a port of the reference PyTorch
+                 path) timed on the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DOMINANT_CFG, DOMINANT_CONV = 0, 1
+DOMINANT_NAME = "opp_gemm_kernel<128,128,2,2,conv> (fp32 MFMA implicit-GEMM 3x3 conv)"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-points", type=int, default=5000)
+    ap.add_argument("--hw", type=int, default=512)
+    ap.add_argument("--fine", action="store_true", help="full coarse-to-fine forward instead of configs[1]")
+    ap.add_argument("--thr", type=float, default=0.1)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config, _lib
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = default_config(thr=args.thr, fine=args.fine)
+    model = OnePosePlus_model(cfg).eval()
+    sd = make_state_dict(cfg, 0) if rank == 0 else None
+    model = model.to(dev)
+    if world > 1:
+        from onepose_plus_plus_amd.sharding import broadcast_weights
+        broadcast_weights(model, sd, src=0)
+    else:
+        model.load_state_dict(sd, strict=True)
+
+    # one synthetic object per rank (seed = rank), a small pool of query images resident in HBM
+    n_img = 4
+    datas = []
+    for i in range(n_img):
+        d = make_inputs(args.n_points, (args.hw, args.hw), seed=1 + 1000 * rank)
+        if i:
+            g = torch.Generator().manual_seed(77 + i + 1000 * rank)
+            d["query_image"] = torch.rand(1, 1, args.hw, args.hw, generator=g)
+        datas.append({k: v.to(dev) for k, v in d.items()})
+    bank = {k: datas[0][k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    for d in datas:
+        d.update(bank)          # the bank is per-object constant: one resident copy
+
+    def step(i):
+        d = dict(datas[i % n_img])
+        with torch.no_grad():
+            model(d)
+        return d
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    lib = _lib.load()
+    prof = (not args.no_roofline) and rank == 0 and world == 1
+    barrier()
+    if prof:
+        _lib.check(lib.opp_profile_start(DOMINANT_CFG, DOMINANT_CONV, args.steps * 8), "profile_start")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    roof = None
+    if prof:
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
+        if n.value > 0 and ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": DOMINANT_NAME,
+                    "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                    "alg_gflop_per_launch": round(fl.value / n.value / 1e9, 3)}
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(cfg, make_state_dict(cfg, 0), args, make_inputs)
+
+    if rank == 0:
+        total = args.steps * world
+        flops_img = 2 * (126.726e9 + 6 * (4096 + args.n_points) * 671744 + args.n_points * 4096 * 256)
+        out = {
+            "metric": "query images/sec (2D-3D match fwd) at 512x512 img x 5k pts",
+            "value": round(total / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random image, descriptor bank and weights)",
+            "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1, "
+                                   "one object per GPU" % (args.hw, args.hw, args.n_points,
+                                                           " + fine refine" if args.fine else ""),
+                       "matches_last_step": int(last["mconf"].numel()),
+                       "model_gflop_per_image": round(flops_img / 1e9, 1),
+                       "model_tflops": round(flops_img * total / elapsed / 1e12, 2),
+                       "model_frac_of_f32_mfma_peak": round(flops_img * total / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, sd, args, make_inputs):
+    """Oracle (port of the reference PyTorch CPU path) timed on the host cores over a bounded
+    sample: as many forwards of the SAME workload as fit in ~cpu_seconds (>= 2)."""
+    from oracle import onepose_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    data = make_inputs(args.n_points, (args.hw, args.hw), seed=1)
+    O.forward(sd, dict(data), cfg)            # warm-up
+    times = []
+    t_end = time.perf_counter() + args.cpu_seconds
+    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 50):
+        d = dict(data)
+        t = time.perf_counter()
+        O.forward(sd, d, cfg)
+        times.append(time.perf_counter() - t)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d forwards of the same 512x512 x %d-pt workload through oracle/onepose_oracle.py "
+                      "(fp32 PyTorch CPU), median; min %.3f s" % (len(times), args.n_points, min(times))}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+/* libopp_hip.so -- C ABI of the MI355X (gfx950) implementation of the OnePose++ 2D-3D
+ * matching forward.
+ *
+ * This is the drop-in boundary UNDER the Python module `onepose_plus_plus_amd.OnePosePlus_model`
+ * (which mirrors the reference's `OnePosePlus_model(config)(data)` API,
+ * /root/reference/src/models/OnePosePlus/OnePosePlusModel.py:25-201).  The reference is pure
+ * Python on PyTorch, so there is no upstream FFI to bind; every entry point below cites the
+ * reference code whose GPU work it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - all tensor pointers are DEVICE pointers to fp32 unless noted; int64 = `long long`.
+ *  - the library never allocates device memory: the caller passes a workspace and the packed
+ *    weight blob (sizes from the *_bytes queries) and owns every buffer.
+ *  - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *    without synchronising; 0 = ok, negative = error (message via opp_last_error()).
+ *  - activations are NHWC ("pixel-major, channel contiguous"); the 196-channel stages are
+ *    padded to 224 channels with zeros.
+ *  - batch size is 1 (the reference's inference path, inference_OnePosePlus_worker.py:52-60).
+ */
+#ifndef OPP_HIP_H
+#define OPP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPP_MAX_LAYERS 16
+
+/* The `model.OnePosePlus` block of configs/experiment/inference_onepose.yaml:26-109, reduced to
+ * the values the kernels depend on. */
+typedef struct opp_config {
+  int initial_dim;         /* loftr_backbone.resnetfpn.initial_dim (128) */
+  int block_dims[3];       /* loftr_backbone.resnetfpn.block_dims (128,196,256) */
+  int kpt_enc_enable;      /* keypoints_encoding.enable */
+  int kpt_enc_dims[3];     /* keypoints_encoding.keypoints_encoder (32,64,128) */
+  int pos_enc_enable;      /* positional_encoding.enable */
+  int coarse_d_model;      /* loftr_coarse.d_model (256) */
+  int coarse_nhead;        /* loftr_coarse.nhead (8) */
+  int coarse_n_layers;     /* len(layer_names) * layer_iter_n (6) */
+  int coarse_is_cross[OPP_MAX_LAYERS]; /* 0 = self, 1 = cross */
+  int fine_d_model;        /* loftr_fine.d_model (128) */
+  int fine_nhead;          /* loftr_fine.nhead (8) */
+  int fine_n_layers;       /* (2) */
+  int fine_is_cross[OPP_MAX_LAYERS];
+  int fine_window;         /* loftr_fine.window_size (5) */
+  float match_thr;         /* coarse_matching.thr */
+  int match_border_rm;     /* coarse_matching.border_rm */
+  float match_temperature; /* coarse_matching.dual_softmax.temperature */
+} opp_config;
+
+typedef struct opp_ctx opp_ctx;
+
+const char* opp_last_error(void);
+int opp_version(void);
+
+/* ---- model handle + weights -------------------------------------------------------------
+ * Replaces: OnePosePlus_model.__init__ + load_state_dict (OnePosePlusModel.py:26-94,
+ * src/inference/inference_OnePosePlus.py:28-38).  Weight tensors are given in the reference
+ * state-dict order without the BatchNorm `num_batches_tracked` counters; opp_weight_name(i)
+ * returns the state-dict key expected at index i. */
+int opp_create(const opp_config* cfg, opp_ctx** out);
+void opp_destroy(opp_ctx* ctx);
+int opp_num_weights(const opp_ctx* ctx);
+const char* opp_weight_name(const opp_ctx* ctx, int i);
+long long opp_weight_numel(const opp_ctx* ctx, int i);
+size_t opp_packed_weights_bytes(const opp_ctx* ctx);
+/* folds eval-mode BatchNorm into the convolutions, re-lays conv weights tap-major/NHWC with
+ * channel padding, concatenates q/k/v projections, transposes the keypoint MLP. */
+int opp_pack_weights(opp_ctx* ctx, const float* const* weights, int n_weights, void* packed,
+                     size_t packed_bytes, void* stream);
+
+/* ---- stages ---------------------------------------------------------------------------- */
+size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W);
+/* ResNetFPN_8_2.forward (backbone/resnet.py:141-164).  image [H][W] in [0,1];
+ * feat_c NHWC [H/8][W/8][256] (x3_out), feat_f NHWC [H/2][W/2][128] (x1_out). */
+int opp_backbone(opp_ctx* ctx, const float* image, int H, int W, float* feat_c, float* feat_f,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* OnePosePlusModel.py:137-156: tokens[0:L] = feat_c + pe (pe NHWC [L][C], may be NULL),
+ * tokens[L:L+N] = bank_c[C][N]^T + MLP(normalize_3d_keypoints(kpts)).  tokens [L+N][C]. */
+int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float* pe, int L, const float* kpts,
+                      const float* bank_c, int n_points, float* tokens, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* LocalFeatureTransformer.forward (loftr_module/transformer.py:133-171), in place on
+ * tokens = [n_seg*len0 rows of stream "2D" ; n_seg*len1 rows of stream "3D"] x d_model.
+ * which = 0: loftr_coarse, 1: loftr_fine. */
+size_t opp_transformer_workspace_bytes(const opp_ctx* ctx, int which, int n_seg, int len0, int len1);
+int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg, int len0, int len1,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* CoarseMatching.forward + get_coarse_match, inference branch (utils/coarse_matching.py:76-242).
+ * feat2d [L][C], feat3d [N][C]; conf [N][L] is written (data['conf_matrix']).  Outputs have
+ * capacity N; *count (device int) receives M.  base_scale = H/hc; query_scale = device pointer to
+ * data['query_image_scale'][0] = (h_scale, w_scale) or NULL. */
+size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n_points, int L);
+int opp_coarse_match(opp_ctx* ctx, const float* feat3d, const float* feat2d, int n_points, int hc,
+                     int wc, const float* kpts, float base_scale, const float* query_scale, float* conf,
+                     long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
+                     float* mkpts_3d, int* count, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Whole coarse level in one call: backbone -> tokens -> loftr_coarse -> coarse matching
+ * (OnePosePlusModel.py:116-167).  feat_f is kept for the fine stage. */
+size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, int W, int n_points);
+int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W, const float* pe,
+                       const float* kpts, const float* bank_c, int n_points, float base_scale,
+                       const float* query_scale, float* feat_f, float* conf, long long* i_ids,
+                       long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d, int* count,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fine level (OnePosePlusModel.py:179-201): FinePreprocess window gather, loftr_fine,
+ * FineMatching.  feat_f NHWC [Hf][Wf][d_fine]; bank_f [d_fine][N] (RAW fine bank, quirk q8);
+ * ids are the first M entries of the coarse outputs.  base_scale = H/Hf; query_scale as above.
+ * run_transformer = config loftr_fine.enable. */
+size_t opp_fine_workspace_bytes(const opp_ctx* ctx, int n_matches);
+int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* bank_f, int n_points,
+             const long long* i_ids, const long long* j_ids, int n_matches, int hc, int wc,
+             const float* mkpts_c, float base_scale, const float* query_scale, int run_transformer,
+             float* expec_f, float* mkpts_f, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
+/* NHWC convolution as implicit GEMM on the fp32 MFMA.  x [Hin][Win][cin_pad]; w_packed
+ * [cout_pad][ks*ks*cin_pad] (from opp_pack_conv_weight); bias [cout_pad] or NULL; residual:
+ * res_mode 0 none, 1 same-shape NHWC [Hout][Wout][cout_pad], 2 bilinear x2 (align_corners)
+ * upsample of NHWC [Hout/2][Wout/2][cout_pad]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
+ * tile_cfg < 0 selects automatically. */
+int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed,
+                    const float* bias, int cout_pad, int ks, int stride, const float* residual,
+                    int res_mode, int act, float* y, int tile_cfg, void* stream);
+int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks,
+                         int cout_pad, int cin_pad, float* out, void* stream);
+/* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU */
+int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,
+               int tile_cfg, void* stream);
+int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
+                   float* out, int rows, int C, void* stream);
+
+/* ---- live kernel timing for bench.py's roofline leg ---------------------------------------
+ * Arms HIP-event timing (events recorded on the launch stream) of every launch of one GEMM /
+ * implicit-conv kernel symbol: tile_cfg 0..4 (128x128, 64x128, 64x64, 128x224, 64x224), conv 1/0.
+ * opp_profile_stop synchronises and returns the summed kernel time, the summed ALGORITHMIC FLOPs
+ * (unpadded channel counts) and the number of launches measured. */
+int opp_profile_start(int tile_cfg, int conv, int capacity_launches);
+int opp_profile_stop(double* total_ms, double* total_flops, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPP_HIP_H */

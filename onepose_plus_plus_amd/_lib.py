@@ -1,0 +1,103 @@
+"""ctypes binding of libopp_hip.so (include/opp_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails the error
+is raised to the caller (the product path never routes through PyTorch ops or the oracle).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopp_hip.so")
+OPP_MAX_LAYERS = 16
+
+
+class OppConfig(Structure):
+    _fields_ = [
+        ("initial_dim", c_int),
+        ("block_dims", c_int * 3),
+        ("kpt_enc_enable", c_int),
+        ("kpt_enc_dims", c_int * 3),
+        ("pos_enc_enable", c_int),
+        ("coarse_d_model", c_int),
+        ("coarse_nhead", c_int),
+        ("coarse_n_layers", c_int),
+        ("coarse_is_cross", c_int * OPP_MAX_LAYERS),
+        ("fine_d_model", c_int),
+        ("fine_nhead", c_int),
+        ("fine_n_layers", c_int),
+        ("fine_is_cross", c_int * OPP_MAX_LAYERS),
+        ("fine_window", c_int),
+        ("match_thr", c_float),
+        ("match_border_rm", c_int),
+        ("match_temperature", c_float),
+    ]
+
+
+# name -> (restype, argtypes).  Must list every symbol declared in include/opp_hip.h
+# (tests/test_cabi.py cross-checks this table against the header).
+SIGNATURES = {
+    "opp_last_error": (c_char_p, []),
+    "opp_version": (c_int, []),
+    "opp_create": (c_int, [POINTER(OppConfig), POINTER(c_void_p)]),
+    "opp_destroy": (None, [c_void_p]),
+    "opp_num_weights": (c_int, [c_void_p]),
+    "opp_weight_name": (c_char_p, [c_void_p, c_int]),
+    "opp_weight_numel": (c_longlong, [c_void_p, c_int]),
+    "opp_packed_weights_bytes": (c_size_t, [c_void_p]),
+    "opp_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
+    "opp_backbone_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "opp_backbone": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_coarse_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    "opp_transformer_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int]),
+    "opp_transformer": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "opp_coarse_match_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "opp_coarse_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "opp_forward_coarse_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_forward_coarse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_fine_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_fine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                         c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                c_int, c_int, c_void_p, c_int, c_void_p]),
+    "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "opp_profile_start": (c_int, [c_int, c_int, c_int]),
+    "opp_profile_stop": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
+}
+
+_lib = None
+
+
+class OppError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libopp_hip.so; raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OppError(
+            "libopp_hip.so not found at %s -- build it with `python -m onepose_plus_plus_amd.build` "
+            "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().opp_last_error()
+        raise OppError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

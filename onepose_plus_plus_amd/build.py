@@ -1,0 +1,70 @@
+"""Builds libopp_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m onepose_plus_plus_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_build")
+LIB = os.path.join(HERE, "libopp_hip.so")
+SOURCES = ["gemm_mfma.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "api.hip"]
+HEADERS = ["opp_common.h", "opp_internal.h", os.path.join("..", "..", "include", "opp_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def compile_one(job):
+        s, o = job
+        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return job, r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            for (s, o), r in ex.map(compile_one, jobs):
+                if verbose and r.stderr.strip():
+                    sys.stderr.write(r.stderr)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed on %s:\n%s" % (s, r.stderr))
+    objs = [os.path.join(OBJ, src.replace(".hip", ".o")) for src in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

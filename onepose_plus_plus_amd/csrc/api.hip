@@ -1,0 +1,812 @@
+// C ABI (include/opp_hip.h): model handle, weight packing, stage orchestration.
+// Mirrors the control flow of OnePosePlus_model.forward
+// (/root/reference/src/models/OnePosePlus/OnePosePlusModel.py:96-201) on one HIP stream.
+#include <math.h>
+#include <stdarg.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/opp_hip.h"
+#include "opp_internal.h"
+
+// ----------------------------------------------------------------------------------------
+// error state
+// ----------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void opp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* opp_last_error(void) { return g_err; }
+extern "C" int opp_version(void) { return 1; }
+
+// ----------------------------------------------------------------------------------------
+// model description
+// ----------------------------------------------------------------------------------------
+namespace {
+
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
+
+struct WeightEntry {
+  std::string name;
+  long long numel;
+};
+
+struct ConvDesc {  // one packed convolution
+  int w_idx = -1;   // weight index in the state-dict table
+  int bn_idx = -1;  // index of <bn>.weight (bias, running_mean, running_var follow) or -1
+  int cin = 0, cout = 0, ks = 1;
+  float* w = nullptr;     // packed [cout_pad][ks*ks*cin_pad]
+  float* bias = nullptr;  // [cout_pad] (folded BN shift) or nullptr
+  int cin_pad() const { return pad32(cin); }
+  int cout_pad() const { return pad32(cout); }
+  size_t w_floats() const { return (size_t)cout_pad() * ks * ks * cin_pad(); }
+};
+
+struct BlockDesc {
+  ConvDesc conv1, conv2, down;
+  bool has_down = false;
+};
+
+struct EncLayerDesc {
+  int q_idx = -1;  // q,k,v,merge,mlp0,mlp2,norm1.w,norm1.b,norm2.w,norm2.b follow consecutively
+  float *wqkv = nullptr, *wmerge = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+};
+
+}  // namespace
+
+struct opp_ctx {
+  opp_config cfg;
+  std::vector<WeightEntry> table;
+  // backbone
+  ConvDesc stem;  // packed as [cout][64]
+  BlockDesc blocks[6];
+  ConvDesc l3_out, l2_out, l2_out2a, l2_out2b, l1_out, l1_out2a, l1_out2b;
+  // keypoint MLP
+  int kpt_idx = -1;
+  float* kpt_wt[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* kpt_b[4] = {nullptr, nullptr, nullptr, nullptr};
+  // transformers
+  std::vector<EncLayerDesc> coarse, fine;
+  bool packed = false;
+  size_t packed_bytes = 0;
+  float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
+};
+
+namespace {
+
+int add_w(opp_ctx* c, const std::string& name, long long numel) {
+  c->table.push_back({name, numel});
+  return (int)c->table.size() - 1;
+}
+int add_bn(opp_ctx* c, const std::string& p, int ch) {
+  const int i = add_w(c, p + ".weight", ch);
+  add_w(c, p + ".bias", ch);
+  add_w(c, p + ".running_mean", ch);
+  add_w(c, p + ".running_var", ch);
+  return i;
+}
+ConvDesc mk_conv(opp_ctx* c, const std::string& name, int cout, int cin, int ks) {
+  ConvDesc d;
+  d.cin = cin;
+  d.cout = cout;
+  d.ks = ks;
+  d.w_idx = add_w(c, name, (long long)cout * cin * ks * ks);
+  return d;
+}
+// state-dict order of BasicBlock: conv1, conv2, bn1, bn2, [downsample.0, downsample.1]
+BlockDesc mk_block(opp_ctx* c, const std::string& p, int cin, int cout, int stride) {
+  BlockDesc b;
+  b.conv1 = mk_conv(c, p + ".conv1.weight", cout, cin, 3);
+  b.conv2 = mk_conv(c, p + ".conv2.weight", cout, cout, 3);
+  b.conv1.bn_idx = add_bn(c, p + ".bn1", cout);
+  b.conv2.bn_idx = add_bn(c, p + ".bn2", cout);
+  if (stride != 1) {
+    b.has_down = true;
+    b.down = mk_conv(c, p + ".downsample.0.weight", cout, cin, 1);
+    b.down.bn_idx = add_bn(c, p + ".downsample.1", cout);
+  }
+  return b;
+}
+void mk_transformer(opp_ctx* c, const std::string& name, int d, int n_layers, std::vector<EncLayerDesc>& out) {
+  for (int i = 0; i < n_layers; ++i) {
+    const std::string p = name + ".layers." + std::to_string(i);
+    EncLayerDesc e;
+    e.q_idx = add_w(c, p + ".q_proj.weight", (long long)d * d);
+    add_w(c, p + ".k_proj.weight", (long long)d * d);
+    add_w(c, p + ".v_proj.weight", (long long)d * d);
+    add_w(c, p + ".merge.weight", (long long)d * d);
+    add_w(c, p + ".mlp.0.weight", (long long)4 * d * d);
+    add_w(c, p + ".mlp.2.weight", (long long)2 * d * d);
+    add_w(c, p + ".norm1.weight", d);
+    add_w(c, p + ".norm1.bias", d);
+    add_w(c, p + ".norm2.weight", d);
+    add_w(c, p + ".norm2.bias", d);
+    out.push_back(e);
+  }
+}
+
+// bump allocator over a caller-provided buffer
+struct Arena {
+  char* base;
+  size_t cap, off = 0;
+  bool ok = true;
+  Arena(void* b, size_t c) : base((char*)b), cap(c) {}
+  float* f(size_t n) { return (float*)raw(n * sizeof(float)); }
+  void* raw(size_t bytes) {
+    const size_t o = opp_align(off);
+    if (base && o + bytes > cap) {
+      ok = false;
+      return base;
+    }
+    off = o + bytes;
+    return base ? base + o : nullptr;
+  }
+};
+
+}  // namespace
+
+extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
+  OPP_CHECK_ARG(cfg && out, "opp_create: null argument");
+  OPP_CHECK_ARG(cfg->initial_dim % 32 == 0 && cfg->initial_dim == cfg->block_dims[0],
+                "unsupported backbone dims: initial_dim %d block_dims[0] %d", cfg->initial_dim, cfg->block_dims[0]);
+  OPP_CHECK_ARG(cfg->block_dims[2] == cfg->coarse_d_model, "block_dims[2] must equal coarse d_model");
+  OPP_CHECK_ARG(cfg->block_dims[0] == cfg->fine_d_model, "block_dims[0] must equal fine d_model");
+  OPP_CHECK_ARG(cfg->coarse_d_model == 256 && cfg->coarse_nhead == 8, "coarse transformer must be d_model 256 / 8 heads");
+  OPP_CHECK_ARG(cfg->fine_d_model == 128 && cfg->fine_nhead == 8, "fine transformer must be d_model 128 / 8 heads");
+  OPP_CHECK_ARG(cfg->coarse_n_layers >= 0 && cfg->coarse_n_layers <= OPP_MAX_LAYERS && cfg->fine_n_layers >= 0 &&
+                    cfg->fine_n_layers <= OPP_MAX_LAYERS, "too many transformer layers");
+  OPP_CHECK_ARG(!cfg->kpt_enc_enable || (cfg->kpt_enc_dims[0] == 32 && cfg->kpt_enc_dims[1] == 64 && cfg->kpt_enc_dims[2] == 128),
+                "keypoint encoder must be [32,64,128]");
+  OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
+  opp_ctx* c = new opp_ctx();
+  c->cfg = *cfg;
+  const int d0 = cfg->initial_dim, d1 = cfg->block_dims[0], d2 = cfg->block_dims[1], d3 = cfg->block_dims[2];
+  // --- same order as the reference state dict (backbone/resnet.py:88-124) ---
+  c->stem = mk_conv(c, "backbone.conv1.weight", d0, 1, 7);
+  c->stem.bn_idx = add_bn(c, "backbone.bn1", d0);
+  c->blocks[0] = mk_block(c, "backbone.layer1.0", d0, d1, 1);
+  c->blocks[1] = mk_block(c, "backbone.layer1.1", d1, d1, 1);
+  c->blocks[2] = mk_block(c, "backbone.layer2.0", d1, d2, 2);
+  c->blocks[3] = mk_block(c, "backbone.layer2.1", d2, d2, 1);
+  c->blocks[4] = mk_block(c, "backbone.layer3.0", d2, d3, 2);
+  c->blocks[5] = mk_block(c, "backbone.layer3.1", d3, d3, 1);
+  c->l3_out = mk_conv(c, "backbone.layer3_outconv.weight", d3, d3, 1);
+  c->l2_out = mk_conv(c, "backbone.layer2_outconv.weight", d3, d2, 1);
+  c->l2_out2a = mk_conv(c, "backbone.layer2_outconv2.0.weight", d3, d3, 3);
+  c->l2_out2a.bn_idx = add_bn(c, "backbone.layer2_outconv2.1", d3);
+  c->l2_out2b = mk_conv(c, "backbone.layer2_outconv2.3.weight", d2, d3, 3);
+  c->l1_out = mk_conv(c, "backbone.layer1_outconv.weight", d2, d1, 1);
+  c->l1_out2a = mk_conv(c, "backbone.layer1_outconv2.0.weight", d2, d2, 3);
+  c->l1_out2a.bn_idx = add_bn(c, "backbone.layer1_outconv2.1", d2);
+  c->l1_out2b = mk_conv(c, "backbone.layer1_outconv2.3.weight", d1, d2, 3);
+  if (cfg->kpt_enc_enable) {  // utils/position_encoding.py:62-79 -> encoder.{0,3,6,9}
+    const int ch[5] = {3, cfg->kpt_enc_dims[0], cfg->kpt_enc_dims[1], cfg->kpt_enc_dims[2], cfg->coarse_d_model};
+    for (int i = 0; i < 4; ++i) {
+      const std::string p = "kpt_3d_pos_encoding.encoder." + std::to_string(3 * i);
+      const int idx = add_w(c, p + ".weight", (long long)ch[i + 1] * ch[i]);
+      add_w(c, p + ".bias", ch[i + 1]);
+      if (i == 0) c->kpt_idx = idx;
+    }
+  }
+  mk_transformer(c, "loftr_coarse", cfg->coarse_d_model, cfg->coarse_n_layers, c->coarse);
+  mk_transformer(c, "loftr_fine", cfg->fine_d_model, cfg->fine_n_layers, c->fine);
+  *out = c;
+  return OPP_OK;
+}
+
+extern "C" void opp_destroy(opp_ctx* ctx) { delete ctx; }
+extern "C" int opp_num_weights(const opp_ctx* ctx) { return ctx ? (int)ctx->table.size() : 0; }
+extern "C" const char* opp_weight_name(const opp_ctx* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->table.size()) ? ctx->table[i].name.c_str() : nullptr;
+}
+extern "C" long long opp_weight_numel(const opp_ctx* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->table.size()) ? ctx->table[i].numel : -1;
+}
+
+// ----------------------------------------------------------------------------------------
+// weight packing
+// ----------------------------------------------------------------------------------------
+namespace {
+
+std::vector<ConvDesc*> all_convs(opp_ctx* c) {
+  std::vector<ConvDesc*> v;
+  for (auto& b : c->blocks) {
+    v.push_back(&b.conv1);
+    v.push_back(&b.conv2);
+    if (b.has_down) v.push_back(&b.down);
+  }
+  for (ConvDesc* d : {&c->l3_out, &c->l2_out, &c->l2_out2a, &c->l2_out2b, &c->l1_out, &c->l1_out2a, &c->l1_out2b}) v.push_back(d);
+  return v;
+}
+
+// lays out (and, with a real base pointer, assigns) every packed tensor
+size_t plan_pack(opp_ctx* c, void* base) {
+  Arena a(base, (size_t)-1);
+  c->scratch_scale = a.f(256);
+  c->stem.w = a.f((size_t)c->stem.cout * 64);
+  c->stem.bias = a.f(pad32(c->stem.cout));
+  for (ConvDesc* d : all_convs(c)) {
+    d->w = a.f(d->w_floats());
+    d->bias = d->bn_idx >= 0 ? a.f(d->cout_pad()) : nullptr;
+  }
+  if (c->cfg.kpt_enc_enable) {
+    const int ch[5] = {3, c->cfg.kpt_enc_dims[0], c->cfg.kpt_enc_dims[1], c->cfg.kpt_enc_dims[2], c->cfg.coarse_d_model};
+    for (int i = 0; i < 4; ++i) {
+      c->kpt_wt[i] = a.f((size_t)ch[i] * ch[i + 1]);
+      c->kpt_b[i] = a.f(ch[i + 1]);
+    }
+  }
+  auto plan_tr = [&](std::vector<EncLayerDesc>& L, int d) {
+    for (auto& e : L) {
+      e.wqkv = a.f((size_t)3 * d * d);
+      e.wmerge = a.f((size_t)d * d);
+      e.w1 = a.f((size_t)4 * d * d);
+      e.w2 = a.f((size_t)2 * d * d);
+      e.g1 = a.f(d);
+      e.b1 = a.f(d);
+      e.g2 = a.f(d);
+      e.b2 = a.f(d);
+    }
+  };
+  plan_tr(c->coarse, c->cfg.coarse_d_model);
+  plan_tr(c->fine, c->cfg.fine_d_model);
+  return opp_align(a.off);
+}
+
+int copy_f(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    opp_set_error("pack: device copy failed");
+    return OPP_ERR_LAUNCH;
+  }
+  return OPP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t opp_packed_weights_bytes(const opp_ctx* ctx) {
+  if (!ctx) return 0;
+  opp_ctx tmp = *ctx;  // plan on a copy (null base -> offsets only)
+  return plan_pack(&tmp, nullptr);
+}
+
+extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* packed, size_t bytes, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  OPP_CHECK_ARG(c && w && packed, "pack: null argument");
+  OPP_CHECK_ARG(n == (int)c->table.size(), "pack: expected %d weight tensors, got %d", (int)c->table.size(), n);
+  const size_t need = plan_pack(c, packed);
+  OPP_CHECK_ARG(bytes >= need, "pack: blob too small (%zu < %zu)", bytes, need);
+  for (int i = 0; i < n; ++i) OPP_CHECK_ARG(w[i] != nullptr, "pack: weight %d (%s) is null", i, c->table[i].name.c_str());
+  const float eps = 1e-5f;
+  auto fold = [&](const ConvDesc& d, float* scale) -> int {
+    const int b = d.bn_idx;
+    return opp_fold_bn(w[b], w[b + 1], w[b + 2], w[b + 3], eps, d.cout, pad32(d.cout), scale, d.bias, s);
+  };
+  // stem (resnet.py:101-103)
+  OPP_TRY(fold(c->stem, c->scratch_scale));
+  OPP_TRY(opp_pack_stem(w[c->stem.w_idx], c->scratch_scale, c->stem.cout, c->stem.w, s));
+  for (ConvDesc* d : all_convs(c)) {
+    const float* scale = nullptr;
+    if (d->bn_idx >= 0) {
+      OPP_TRY(fold(*d, c->scratch_scale));
+      scale = c->scratch_scale;
+    }
+    OPP_TRY(opp_pack_conv(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), d->w, s));
+  }
+  if (c->cfg.kpt_enc_enable) {
+    const int ch[5] = {3, c->cfg.kpt_enc_dims[0], c->cfg.kpt_enc_dims[1], c->cfg.kpt_enc_dims[2], c->cfg.coarse_d_model};
+    for (int i = 0; i < 4; ++i) {
+      // PyTorch Linear weight [Cout][Cin] -> [Cin][Cout]
+      OPP_TRY(opp_transpose(w[c->kpt_idx + 2 * i], c->kpt_wt[i], 1, ch[i + 1], ch[i], s));
+      OPP_TRY(copy_f(c->kpt_b[i], w[c->kpt_idx + 2 * i + 1], ch[i + 1], s));
+    }
+  }
+  auto pack_tr = [&](std::vector<EncLayerDesc>& L, int d) -> int {
+    for (auto& e : L) {
+      const int q = e.q_idx;
+      const size_t dd = (size_t)d * d;
+      OPP_TRY(copy_f(e.wqkv, w[q], dd, s));
+      OPP_TRY(copy_f(e.wqkv + dd, w[q + 1], dd, s));
+      OPP_TRY(copy_f(e.wqkv + 2 * dd, w[q + 2], dd, s));
+      OPP_TRY(copy_f(e.wmerge, w[q + 3], dd, s));
+      OPP_TRY(copy_f(e.w1, w[q + 4], 4 * dd, s));
+      OPP_TRY(copy_f(e.w2, w[q + 5], 2 * dd, s));
+      OPP_TRY(copy_f(e.g1, w[q + 6], d, s));
+      OPP_TRY(copy_f(e.b1, w[q + 7], d, s));
+      OPP_TRY(copy_f(e.g2, w[q + 8], d, s));
+      OPP_TRY(copy_f(e.b2, w[q + 9], d, s));
+    }
+    return OPP_OK;
+  };
+  OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
+  OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
+  c->packed = true;
+  c->packed_bytes = need;
+  return OPP_OK;
+}
+
+// ----------------------------------------------------------------------------------------
+// backbone
+// ----------------------------------------------------------------------------------------
+namespace {
+
+int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
+             float* y, hipStream_t s, int tile_cfg = -1) {
+  OppGemm g;
+  g.conv = 1;
+  g.A0 = x;
+  g.Bn = 1;
+  g.Hin = Hin;
+  g.Win = Win;
+  g.Cin = d.cin_pad();
+  g.ksize = d.ks;
+  g.stride = stride;
+  g.pad = d.ks / 2;
+  g.Hout = (Hin + 2 * g.pad - d.ks) / stride + 1;
+  g.Wout = (Win + 2 * g.pad - d.ks) / stride + 1;
+  g.W = d.w;
+  g.ldw = d.ks * d.ks * d.cin_pad();
+  g.M = g.Hout * g.Wout;
+  g.N = d.cout_pad();
+  g.K = g.ldw;
+  g.C = y;
+  g.ldc = d.cout_pad();
+  g.n_store = d.cout_pad();
+  g.bias = d.bias;
+  g.res_mode = res_mode;
+  g.R = res;
+  g.ldr = d.cout_pad();
+  if (res_mode == OPP_RES_BILINEAR2X) {
+    g.Hr = g.Hout / 2;
+    g.Wr = g.Wout / 2;
+    // align_corners=True source index scale (in-1)/(out-1), resnet.py:151,155
+    g.res_sy = g.Hout > 1 ? (float)(g.Hr - 1) / (float)(g.Hout - 1) : 0.f;
+    g.res_sx = g.Wout > 1 ? (float)(g.Wr - 1) / (float)(g.Wout - 1) : 0.f;
+  }
+  g.act = act;
+  g.alg_flops = 2.0 * (double)g.M * (double)d.cout * (double)(d.ks * d.ks * d.cin);
+  return opp_gemm_launch_cfg(g, tile_cfg, s);
+}
+
+// BasicBlock.forward (resnet.py:37-45)
+int run_block(const float* x, int Hin, int Win, const BlockDesc& b, int stride, float* tmp, float* ds, float* y,
+              hipStream_t s) {
+  const int Ho = Hin / stride, Wo = Win / stride;
+  OPP_TRY(run_conv(x, Hin, Win, b.conv1, stride, nullptr, OPP_RES_NONE, OPP_ACT_RELU, tmp, s));
+  const float* shortcut = x;
+  if (b.has_down) {
+    OPP_TRY(run_conv(x, Hin, Win, b.down, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, ds, s));
+    shortcut = ds;
+  }
+  return run_conv(tmp, Ho, Wo, b.conv2, 1, shortcut, OPP_RES_DIRECT, OPP_ACT_RELU, y, s);
+}
+
+struct BackboneBufs {
+  float *col, *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *l2, *u2, *x2o, *l1, *u1;
+};
+
+size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) {
+  const size_t p2 = (size_t)(H / 2) * (W / 2), p4 = (size_t)(H / 4) * (W / 4), p8 = (size_t)(H / 8) * (W / 8);
+  const int c1 = pad32(c->cfg.block_dims[0]), c2 = pad32(c->cfg.block_dims[1]), c3 = pad32(c->cfg.block_dims[2]);
+  b.col = a.f(p2 * 64);
+  b.x0 = a.f(p2 * c1);
+  b.t1 = a.f(p2 * c1);
+  b.x1a = a.f(p2 * c1);
+  b.x1 = a.f(p2 * c1);
+  b.t2 = a.f(p4 * c2);
+  b.ds2 = a.f(p4 * c2);
+  b.x2a = a.f(p4 * c2);
+  b.x2 = a.f(p4 * c2);
+  b.t3 = a.f(p8 * c3);
+  b.ds3 = a.f(p8 * c3);
+  b.x3a = a.f(p8 * c3);
+  b.x3 = a.f(p8 * c3);
+  b.l2 = a.f(p4 * c3);
+  b.u2 = a.f(p4 * c3);
+  b.x2o = a.f(p4 * c2);
+  b.l1 = a.f(p2 * c2);
+  b.u1 = a.f(p2 * c2);
+  return a.off;
+}
+
+int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s) {
+  OPP_CHECK_ARG(c && c->packed, "backbone: weights not packed");
+  OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone: H,W must be multiples of 8 (got %dx%d)", H, W);
+  BackboneBufs b;
+  plan_backbone(c, H, W, a, b);
+  if (!a.ok) {
+    opp_set_error("backbone: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
+  OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
+  {
+    OppGemm g;
+    g.A0 = b.col;
+    g.lda0 = 64;
+    g.ksplit = 64;
+    g.W = c->stem.w;
+    g.ldw = 64;
+    g.M = H2 * W2;
+    g.N = c->stem.cout;
+    g.K = 64;
+    g.C = b.x0;
+    g.ldc = pad32(c->stem.cout);
+    g.n_store = pad32(c->stem.cout);
+    g.bias = c->stem.bias;
+    g.act = OPP_ACT_RELU;
+    OPP_TRY(opp_gemm_launch(g, s));
+  }
+  OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s));   // layer1 (:144)
+  OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s));
+  OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s));     // layer2 (:145)
+  OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s));
+  OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s));     // layer3 (:146)
+  OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s));
+  // FPN (:149-157)
+  OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s));
+  OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s));
+  OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s));
+  OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s));
+  OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s));
+  OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s));
+  OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s));
+  return OPP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  BackboneBufs b;
+  return opp_align(plan_backbone(ctx, H, W, a, b)) + 256;
+}
+
+extern "C" int opp_backbone(opp_ctx* ctx, const float* image, int H, int W, float* feat_c, float* feat_f, void* ws,
+                            size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && image && feat_c && feat_f && ws, "backbone: null argument");
+  Arena a(ws, ws_bytes);
+  return backbone_impl(ctx, image, H, W, feat_c, feat_f, a, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// tokens, transformer
+// ----------------------------------------------------------------------------------------
+namespace {
+
+int coarse_tokens_impl(opp_ctx* c, const float* feat_c, const float* pe, int L, const float* kpts, const float* bank_c,
+                       int n, float* tokens, Arena& a, hipStream_t s) {
+  const int C = c->cfg.coarse_d_model;
+  float* stats = a.f(8);
+  if (!a.ok) {
+    opp_set_error("coarse_tokens: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  if (pe) {
+    OPP_TRY(opp_add(feat_c, pe, tokens, (size_t)L * C, s));   // OnePosePlusModel.py:137-142
+  } else if (hipMemcpyAsync(tokens, feat_c, (size_t)L * C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    opp_set_error("coarse_tokens: copy failed");
+    return OPP_ERR_LAUNCH;
+  }
+  float* t3 = tokens + (size_t)L * C;
+  if (c->cfg.kpt_enc_enable) {
+    OPP_TRY(opp_kpt_stats(kpts, n, stats, s));               // utils/normalize.py:16-26
+    OPP_TRY(opp_kpt_encode(kpts, stats, bank_c, n, c->kpt_wt, c->kpt_b, t3, C, s));
+  } else {
+    OPP_TRY(opp_bank_transpose(bank_c, n, C, t3, C, s));
+  }
+  return OPP_OK;
+}
+
+struct TrBufs {
+  float *qkv, *msg, *mrg, *hid, *kv, *ks, *scratch;
+};
+
+size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, TrBufs& b) {
+  const size_t T = (size_t)n_seg * (len0 + len1);
+  b.qkv = a.f(T * 3 * C);
+  b.msg = a.f(T * C);
+  b.mrg = a.f(T * C);
+  b.hid = a.f(T * 2 * C);
+  b.kv = a.f((size_t)2 * n_seg * C * D);
+  b.ks = a.f((size_t)2 * n_seg * C);
+  const int ch = opp_linattn_chunks(len0) > opp_linattn_chunks(len1) ? opp_linattn_chunks(len0) : opp_linattn_chunks(len1);
+  b.scratch = a.f((size_t)n_seg * ch * (C * D + C));
+  return a.off;
+}
+
+int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit, const float* W, int M, int N, int K, float* C,
+               int act, hipStream_t s) {
+  OppGemm g;
+  g.A0 = A0;
+  g.lda0 = lda0;
+  g.A1 = A1;
+  g.lda1 = lda1;
+  g.ksplit = ksplit;
+  g.W = W;
+  g.ldw = K;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.C = C;
+  g.ldc = N;
+  g.n_store = N;
+  g.act = act;
+  return opp_gemm_launch(g, s);
+}
+
+// LocalFeatureTransformer.forward (transformer.py:133-171) on X = [stream0 ; stream1]
+int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cross, int C, int nhead, float* X, int n_seg,
+                     int len0, int len1, Arena& a, hipStream_t s) {
+  const int D = C / nhead;
+  const int T0 = n_seg * len0, T1 = n_seg * len1, T = T0 + T1;
+  if (T == 0 || layers.empty()) return OPP_OK;
+  TrBufs b;
+  plan_transformer(C, D, n_seg, len0, len1, a, b);
+  if (!a.ok) {
+    opp_set_error("transformer: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  float* kv0 = b.kv;
+  float* kv1 = b.kv + (size_t)n_seg * C * D;
+  float* ks0 = b.ks;
+  float* ks1 = b.ks + (size_t)n_seg * C;
+  const float eps_attn = 1e-6f, eps_ln = 1e-5f;
+  for (size_t li = 0; li < layers.size(); ++li) {
+    const EncLayerDesc& e = layers[li];
+    const bool cross = is_cross[li] != 0;
+    {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
+      OppGemm g;
+      g.A0 = X;
+      g.lda0 = C;
+      g.ksplit = C;
+      g.W = e.wqkv;
+      g.ldw = C;
+      g.M = T;
+      g.N = 3 * C;
+      g.K = C;
+      g.C = b.qkv;
+      g.ldc = 3 * C;
+      g.n_store = 3 * C;
+      g.act = OPP_ACT_QKV;
+      g.qk_cols = 2 * C;
+      g.split_row = T0;
+      g.s0 = (float)len0;
+      g.s1 = (float)len1;
+      OPP_TRY(opp_gemm_launch(g, s));
+    }
+    const float* q0 = b.qkv;
+    const float* q1 = b.qkv + (size_t)T0 * 3 * C;
+    OPP_TRY(opp_linattn_kv(q0 + C, q0 + 2 * C, 3 * C, n_seg, len0, C, D, kv0, ks0, b.scratch, s));
+    OPP_TRY(opp_linattn_kv(q1 + C, q1 + 2 * C, 3 * C, n_seg, len1, C, D, kv1, ks1, b.scratch, s));
+    // self: each stream attends to itself; cross: to the other stream's (pre-update) K,V (quirk q6)
+    OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, b.msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps_attn, s));
+    OPP_TRY(opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, b.msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps_attn, s));
+    OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s));          // merge (:86)
+    OPP_TRY(opp_layernorm(b.mrg, C, e.g1, e.b1, nullptr, 0, b.msg, C, T, C, eps_ln, s));              // norm1 (:87)
+    OPP_TRY(dense_gemm(X, C, b.msg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s));            // mlp.0 on cat([x,msg]) (:91)
+    OPP_TRY(dense_gemm(b.hid, 2 * C, nullptr, 0, 2 * C, e.w2, T, C, 2 * C, b.mrg, OPP_ACT_NONE, s));  // mlp.2
+    OPP_TRY(opp_layernorm(b.mrg, C, e.g2, e.b2, X, C, X, C, T, C, eps_ln, s));                        // x + norm2 (:92-94)
+  }
+  return OPP_OK;
+}
+
+}  // namespace
+
+extern "C" int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float* pe, int L, const float* kpts,
+                                 const float* bank_c, int n, float* tokens, void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && ctx->packed && feat_c && kpts && bank_c && tokens && ws, "coarse_tokens: null argument");
+  OPP_CHECK_ARG(L > 0 && n > 0, "coarse_tokens: empty input");
+  Arena a(ws, ws_bytes);
+  return coarse_tokens_impl(ctx, feat_c, pe, L, kpts, bank_c, n, tokens, a, (hipStream_t)stream);
+}
+
+extern "C" size_t opp_transformer_workspace_bytes(const opp_ctx* ctx, int which, int n_seg, int len0, int len1) {
+  if (!ctx) return 0;
+  const int C = which == 0 ? ctx->cfg.coarse_d_model : ctx->cfg.fine_d_model;
+  const int nh = which == 0 ? ctx->cfg.coarse_nhead : ctx->cfg.fine_nhead;
+  Arena a(nullptr, 0);
+  TrBufs b;
+  return opp_align(plan_transformer(C, C / nh, n_seg, len0, len1, a, b)) + 256;
+}
+
+extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg, int len0, int len1, void* ws,
+                               size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && ctx->packed && tokens && ws, "transformer: null argument");
+  OPP_CHECK_ARG(which == 0 || which == 1, "transformer: which must be 0 or 1");
+  Arena a(ws, ws_bytes);
+  if (which == 0)
+    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream);
+  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// coarse matching
+// ----------------------------------------------------------------------------------------
+namespace {
+
+int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts, float base_scale,
+                      const float* qscale, float* conf, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
+                      float* mkpts_3d, int* count, Arena& a, hipStream_t s) {
+  const int C = c->cfg.coarse_d_model, L = hc * wc;
+  float* scratch = a.f(opp_coarse_match_scratch_floats(n, L));
+  if (!a.ok) {
+    opp_set_error("coarse_match: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  // sim = (f3/sqrt(C)) . (f2/sqrt(C)) / (temperature + 1e-4)   (coarse_matching.py:99-107).
+  // C = 256: the 1/16 feature scaling is an exact power of two, so it commutes with the sum.
+  OppGemm g;
+  g.A0 = f3;
+  g.lda0 = C;
+  g.ksplit = C;
+  g.W = f2;
+  g.ldw = C;
+  g.M = n;
+  g.N = L;
+  g.K = C;
+  g.C = conf;
+  g.ldc = L;
+  g.n_store = L;
+  g.out_mul = 1.0f / (float)C;
+  g.out_div = (float)((double)c->cfg.match_temperature + 1e-4);
+  OPP_TRY(opp_gemm_launch(g, s));
+  return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, scratch, i_ids, j_ids,
+                                 mconf, mkpts_c, mkpts_3d, count, s);
+}
+
+}  // namespace
+
+extern "C" size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n, int L) {
+  (void)ctx;
+  return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) + 512;
+}
+
+extern "C" int opp_coarse_match(opp_ctx* ctx, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts,
+                                float base_scale, const float* qscale, float* conf, long long* i_ids, long long* j_ids, float* mconf,
+                                float* mkpts_c, float* mkpts_3d, int* count, void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && f3 && f2 && kpts && conf && i_ids && j_ids && mconf && mkpts_c && mkpts_3d && count && ws,
+                "coarse_match: null argument");
+  OPP_CHECK_ARG(n > 0 && hc > 0 && wc > 0, "coarse_match: empty input");
+  Arena a(ws, ws_bytes);
+  return coarse_match_impl(ctx, f3, f2, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count, a,
+                           (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------
+// whole coarse level
+// ----------------------------------------------------------------------------------------
+namespace {
+
+size_t plan_forward_coarse(const opp_ctx* c, int H, int W, int n, Arena& a, float** feat_c, float** tokens) {
+  const int C = c->cfg.coarse_d_model;
+  const size_t L = (size_t)(H / 8) * (W / 8);
+  *feat_c = a.f(L * C);
+  *tokens = a.f((L + n) * C);
+  return a.off;
+}
+
+}  // namespace
+
+extern "C" size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, int W, int n) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  float *fc, *tk;
+  size_t base = opp_align(plan_forward_coarse(ctx, H, W, n, a, &fc, &tk));
+  const int L = (H / 8) * (W / 8);
+  size_t s1 = opp_backbone_workspace_bytes(ctx, H, W);
+  size_t s2 = opp_transformer_workspace_bytes(ctx, 0, 1, L, n);
+  size_t s3 = opp_coarse_match_workspace_bytes(ctx, n, L);
+  size_t m = s1 > s2 ? s1 : s2;
+  m = m > s3 ? m : s3;
+  return base + m + 1024;
+}
+
+extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W, const float* pe, const float* kpts,
+                                  const float* bank_c, int n, float base_scale, const float* qscale, float* feat_f, float* conf,
+                                  long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d,
+                                  int* count, void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && bank_c && feat_f && conf && ws, "forward_coarse: null argument");
+  OPP_CHECK_ARG(n > 0, "forward_coarse: empty point cloud");
+  OPP_CHECK_ARG(!ctx->cfg.pos_enc_enable || pe, "forward_coarse: positional encoding enabled but pe is null");
+  hipStream_t s = (hipStream_t)stream;
+  Arena a(ws, ws_bytes);
+  float *feat_c, *tokens;
+  plan_forward_coarse(ctx, H, W, n, a, &feat_c, &tokens);
+  if (!a.ok) {
+    opp_set_error("forward_coarse: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  const size_t mark = a.off;
+  const int hc = H / 8, wc = W / 8, L = hc * wc, C = ctx->cfg.coarse_d_model;
+  OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
+  a.off = mark;
+  OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens, a, s));
+  a.off = mark;
+  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s));
+  a.off = mark;
+  return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
+                           mkpts_3d, count, a, s);
+}
+
+// ----------------------------------------------------------------------------------------
+// fine level
+// ----------------------------------------------------------------------------------------
+extern "C" size_t opp_fine_workspace_bytes(const opp_ctx* ctx, int M) {
+  if (!ctx || M <= 0) return 256;
+  const int C = ctx->cfg.fine_d_model, WW = ctx->cfg.fine_window * ctx->cfg.fine_window;
+  return opp_align((size_t)M * (WW + 1) * C * sizeof(float)) + opp_transformer_workspace_bytes(ctx, 1, M, WW, 1) + 1024;
+}
+
+extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* bank_f, int n, const long long* i_ids,
+                        const long long* j_ids, int M, int hc, int wc, const float* mkpts_c, float base_scale,
+                        const float* qscale, int run_transformer, float* expec_f, float* mkpts_f, void* ws, size_t ws_bytes, void* stream) {
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(ctx && ctx->packed && feat_f && bank_f && i_ids && j_ids && mkpts_c && expec_f && mkpts_f && ws,
+                "fine: null argument");
+  OPP_CHECK_ARG(hc > 0 && Hf % hc == 0, "fine: fine map height %d not a multiple of coarse %d", Hf, hc);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = ctx->cfg.fine_d_model, Wwin = ctx->cfg.fine_window, WW = Wwin * Wwin;
+  Arena a(ws, ws_bytes);
+  float* X = a.f((size_t)M * (WW + 1) * C);  // [M*WW window tokens ; M point tokens]
+  if (!a.ok) {
+    opp_set_error("fine: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  float* f3 = X + (size_t)M * WW * C;
+  OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
+  if (run_transformer)
+    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s));
+  const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
+  return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
+}
+
+// ----------------------------------------------------------------------------------------
+// building blocks
+// ----------------------------------------------------------------------------------------
+extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed, const float* bias,
+                               int cout_pad, int ks, int stride, const float* residual, int res_mode, int act, float* y,
+                               int tile_cfg, void* stream) {
+  OPP_CHECK_ARG(x && w_packed && y, "conv2d: null argument");
+  OPP_CHECK_ARG(cin_pad % 32 == 0 && cout_pad % 32 == 0, "conv2d: channel counts must be padded to 32");
+  ConvDesc d;
+  d.cin = cin_pad;
+  d.cout = cout_pad;
+  d.ks = ks;
+  d.w = const_cast<float*>(w_packed);
+  d.bias = const_cast<float*>(bias);
+  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, tile_cfg);
+}
+
+extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
+                                    float* out, void* stream) {
+  return opp_pack_conv(w, scale, cout, cin, ks, cout_pad, cin_pad, out, (hipStream_t)stream);
+}
+
+extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, void* stream) {
+  OppGemm g;
+  g.A0 = A;
+  g.lda0 = K;
+  g.ksplit = K;
+  g.W = W;
+  g.ldw = K;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.C = C;
+  g.ldc = N;
+  g.n_store = N;
+  g.act = act;
+  return opp_gemm_launch_cfg(g, tile_cfg, (hipStream_t)stream);
+}
+
+extern "C" int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                              int rows, int C, void* stream) {
+  return opp_layernorm(x, C, gamma, beta, residual, C, out, C, rows, C, 1e-5f, (hipStream_t)stream);
+}

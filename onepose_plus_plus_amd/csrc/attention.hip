@@ -1,0 +1,269 @@
+// LayerNorm and the linear-attention core (elu+1 kernel feature map) for gfx950.
+//
+// Reference:
+//   LinearAttention.forward   src/models/OnePosePlus/loftr_module/linear_attention.py:29-61
+//   LoFTREncoderLayer.forward src/models/OnePosePlus/loftr_module/transformer.py:65-94
+//
+// The q/k/v projections, merge and MLP are GEMMs (gemm_mfma.hip); their epilogue already
+// applied phi(x) = elu(x)+1 to Q and K and divided V by the source length.  What is left
+// here is HBM-bound: the per-head reduction KV = sum_s phi(K_s)^T V_s, Ksum = sum_s phi(K_s)
+// over the S source tokens (reads K,V once: S * 2 * C * 4 bytes), and the per-token apply
+// out = (phi(Q) KV) / (phi(Q).Ksum + eps) * S.
+//
+// Token streams are regular: a stream is [n_seg][seg_len][ld] (coarse: one segment of 4096
+// image cells and one of N points; fine: M segments of 25 window cells and M of 1 point).
+#include "opp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the last dim (C = 64*VPT), one wave per row, optional residual add:
+//   out = (res ? res : 0) + (x - mean) / sqrt(var + eps) * gamma + beta
+// transformer.py:88 (norm1) and :93-94 (norm2 + residual).
+// ---------------------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ res, int ldres,
+                                                        float* __restrict__ out, int ldo, int rows,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  constexpr int C = 64 * VPT;
+  float v[VPT];
+  const float* xr = x + (size_t)row * ldx + lane * VPT;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) v[i] = xr[i];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) s += v[i];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const float d = v[i] - mean;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  float* orow = out + (size_t)row * ldo + lane * VPT;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    float y = (v[i] - mean) * rstd * gamma[lane * VPT + i] + beta[lane * VPT + i];
+    if (res) y = res[(size_t)row * ldres + lane * VPT + i] + y;
+    orow[i] = y;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// KV / Ksum partial reduction.  Block = C threads; thread t <-> (head h = t / D, column v = t % D)
+// keeps KV[h][0..D-1][v] in registers.  grid = (chunks_per_seg, n_seg).
+//   kv_part [seg][chunk][h][d][v]   ks_part [seg][chunk][h*D + d]
+// ---------------------------------------------------------------------------------------
+template <int D, int C>
+__global__ __launch_bounds__(C) void linattn_kv_partial_kernel(const float* __restrict__ kmat,
+                                                               const float* __restrict__ vmat, int ld,
+                                                               int seg_len, int chunk_len,
+                                                               float* __restrict__ kv_part,
+                                                               float* __restrict__ ks_part) {
+  constexpr int TB = 8;  // tokens staged per barrier
+  __shared__ __attribute__((aligned(16))) float ksh[TB][C];
+  const int t = threadIdx.x;
+  const int h = t / D;
+  const int chunk = blockIdx.x;
+  const int seg = blockIdx.y;
+  const int s_begin = chunk * chunk_len;
+  const int s_end = min(seg_len, s_begin + chunk_len);
+  const size_t base = (size_t)seg * seg_len;
+
+  float acc[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) acc[d] = 0.f;
+  float ksum = 0.f;
+
+  for (int s0 = s_begin; s0 < s_end; s0 += TB) {
+    float vv[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int s = s0 + j;
+      float kval = 0.f, vval = 0.f;
+      if (s < s_end) {
+        kval = kmat[(base + s) * ld + t];
+        vval = vmat[(base + s) * ld + t];
+      }
+      ksh[j][t] = kval;
+      vv[j] = vval;
+      ksum += kval;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const float4* kr = reinterpret_cast<const float4*>(&ksh[j][h * D]);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 k4 = kr[d4];
+        acc[d4 * 4 + 0] = fmaf(k4.x, vv[j], acc[d4 * 4 + 0]);
+        acc[d4 * 4 + 1] = fmaf(k4.y, vv[j], acc[d4 * 4 + 1]);
+        acc[d4 * 4 + 2] = fmaf(k4.z, vv[j], acc[d4 * 4 + 2]);
+        acc[d4 * 4 + 3] = fmaf(k4.w, vv[j], acc[d4 * 4 + 3]);
+      }
+    }
+    __syncthreads();
+  }
+  const size_t p = (size_t)seg * gridDim.x + chunk;
+  float* kvp = kv_part + p * (size_t)(C * D);
+  const int v = t % D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) kvp[(h * D + d) * D + v] = acc[d];
+  ks_part[p * C + t] = ksum;
+}
+
+// fixed-order sum of the chunk partials (deterministic): out[seg][i] = sum_c part[seg][c][i]
+__global__ void linattn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                      int n_chunks, int width) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int seg = blockIdx.y;
+  if (i >= width) return;
+  const float* p = part + (size_t)seg * n_chunks * width + i;
+  float s = 0.f;
+  for (int c = 0; c < n_chunks; ++c) s += p[(size_t)c * width];
+  out[(size_t)seg * width + i] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// apply: msg[l][h*D + v] = (sum_d Q[l,h,d] KV[h,d,v]) * (1 / (sum_d Q[l,h,d] Ksum[h,d] + eps)) * S
+// grid = (chunks_per_seg, n_seg); the segment index selects the KV of the SOURCE stream.
+// ---------------------------------------------------------------------------------------
+template <int D, int C>
+__global__ __launch_bounds__(C) void linattn_apply_kernel(const float* __restrict__ qmat, int ldq,
+                                                          const float* __restrict__ kv,
+                                                          const float* __restrict__ ks,
+                                                          float* __restrict__ out, int ldo,
+                                                          int seg_len, int chunk_len, float src_len,
+                                                          float eps) {
+  constexpr int TB = 8;
+  __shared__ __attribute__((aligned(16))) float qsh[TB][C];
+  const int t = threadIdx.x;
+  const int h = t / D;
+  const int v = t % D;
+  const int seg = blockIdx.y;
+  const int s_begin = blockIdx.x * chunk_len;
+  const int s_end = min(seg_len, s_begin + chunk_len);
+  const size_t base = (size_t)seg * seg_len;
+
+  float kvr[D], ksr[D];
+  const float* kvp = kv + (size_t)seg * (C * D);
+  const float* ksp = ks + (size_t)seg * C;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    kvr[d] = kvp[(h * D + d) * D + v];
+    ksr[d] = ksp[h * D + d];
+  }
+  for (int s0 = s_begin; s0 < s_end; s0 += TB) {
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int s = s0 + j;
+      qsh[j][t] = s < s_end ? qmat[(base + s) * ldq + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int s = s0 + j;
+      if (s >= s_end) break;
+      const float4* qr = reinterpret_cast<const float4*>(&qsh[j][h * D]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 q4 = qr[d4];
+        num = fmaf(q4.x, kvr[d4 * 4 + 0], num);
+        den = fmaf(q4.x, ksr[d4 * 4 + 0], den);
+        num = fmaf(q4.y, kvr[d4 * 4 + 1], num);
+        den = fmaf(q4.y, ksr[d4 * 4 + 1], den);
+        num = fmaf(q4.z, kvr[d4 * 4 + 2], num);
+        den = fmaf(q4.z, ksr[d4 * 4 + 2], den);
+        num = fmaf(q4.w, kvr[d4 * 4 + 3], num);
+        den = fmaf(q4.w, ksr[d4 * 4 + 3], den);
+      }
+      const float z = 1.0f / (den + eps);
+      out[(base + s) * ldo + t] = (num * z) * src_len;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res,
+                  int ldres, float* out, int ldo, int rows, int C, float eps, hipStream_t stream) {
+  if (rows <= 0) return OPP_OK;
+  dim3 grid(opp_cdiv(rows, 4)), block(256);
+  if (C == 256)
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, res, ldres, out, ldo, rows, eps);
+  else if (C == 128)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, ldx, gamma, beta, res, ldres, out, ldo, rows, eps);
+  else {
+    opp_set_error("layernorm: unsupported width %d", C);
+    return OPP_ERR_UNSUPPORTED;
+  }
+  OPP_CHECK_LAUNCH("layernorm_kernel");
+  return OPP_OK;
+}
+
+// number of chunk partials the kv reduction uses for a stream of `seg_len` tokens per segment
+int opp_linattn_chunks(int seg_len) {
+  const int chunk = 64;
+  return seg_len <= chunk ? 1 : opp_cdiv(seg_len, chunk);
+}
+
+// KV/Ksum of one stream.  k/v point at the K / V columns of the stream's first token
+// (row stride ld).  kv_out [n_seg][C*D], ks_out [n_seg][C]; scratch must hold
+// n_seg * chunks * (C*D + C) floats when chunks > 1.
+int opp_linattn_kv(const float* k, const float* v, int ld, int n_seg, int seg_len, int C, int D,
+                   float* kv_out, float* ks_out, float* scratch, hipStream_t stream) {
+  if (n_seg <= 0 || seg_len <= 0) return OPP_OK;
+  const int chunks = opp_linattn_chunks(seg_len);
+  const int chunk_len = chunks == 1 ? seg_len : 64;
+  float* kvp = chunks == 1 ? kv_out : scratch;
+  float* ksp = chunks == 1 ? ks_out : scratch + (size_t)n_seg * chunks * C * D;
+  dim3 grid(chunks, n_seg);
+  if (C == 256 && D == 32)
+    hipLaunchKernelGGL((linattn_kv_partial_kernel<32, 256>), grid, dim3(256), 0, stream, k, v, ld, seg_len, chunk_len, kvp, ksp);
+  else if (C == 128 && D == 16)
+    hipLaunchKernelGGL((linattn_kv_partial_kernel<16, 128>), grid, dim3(128), 0, stream, k, v, ld, seg_len, chunk_len, kvp, ksp);
+  else {
+    opp_set_error("linattn: unsupported (C=%d, D=%d)", C, D);
+    return OPP_ERR_UNSUPPORTED;
+  }
+  OPP_CHECK_LAUNCH("linattn_kv_partial_kernel");
+  if (chunks > 1) {
+    hipLaunchKernelGGL(linattn_reduce_kernel, dim3(opp_cdiv(C * D, 256), n_seg), dim3(256), 0, stream, kvp, kv_out, chunks, C * D);
+    hipLaunchKernelGGL(linattn_reduce_kernel, dim3(opp_cdiv(C, 256), n_seg), dim3(256), 0, stream, ksp, ks_out, chunks, C);
+    OPP_CHECK_LAUNCH("linattn_reduce_kernel");
+  }
+  return OPP_OK;
+}
+
+int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks, float* out, int ldo,
+                      int n_seg, int seg_len, int src_len, int C, int D, float eps, hipStream_t stream) {
+  if (n_seg <= 0 || seg_len <= 0) return OPP_OK;
+  const int chunk_len = 32;
+  dim3 grid(opp_cdiv(seg_len, chunk_len), n_seg);
+  if (C == 256 && D == 32)
+    hipLaunchKernelGGL((linattn_apply_kernel<32, 256>), grid, dim3(256), 0, stream, q, ldq, kv, ks, out, ldo, seg_len, chunk_len, (float)src_len, eps);
+  else if (C == 128 && D == 16)
+    hipLaunchKernelGGL((linattn_apply_kernel<16, 128>), grid, dim3(128), 0, stream, q, ldq, kv, ks, out, ldo, seg_len, chunk_len, (float)src_len, eps);
+  else {
+    opp_set_error("linattn: unsupported (C=%d, D=%d)", C, D);
+    return OPP_ERR_UNSUPPORTED;
+  }
+  OPP_CHECK_LAUNCH("linattn_apply_kernel");
+  return OPP_OK;
+}

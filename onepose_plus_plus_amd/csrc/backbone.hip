@@ -1,0 +1,149 @@
+// Backbone-side helper kernels: weight packing (BN folding, NHWC/tap-major layout, channel
+// padding 196 -> 224), the 7x7/s2 stem im2col, and the positional-encoding add.
+//
+// Reference: ResNetFPN_8_2  src/models/OnePosePlus/backbone/resnet.py:85-164
+//            PositionEncodingSine.forward  src/models/OnePosePlus/utils/position_encoding.py:37-42
+#include "opp_common.h"
+
+namespace {
+
+// eval BatchNorm as y = x*scale + shift  (resnet.py:25-26; eps 1e-5)
+__global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var,
+                               float eps, int c, int c_pad, float* __restrict__ scale,
+                               float* __restrict__ shift) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c_pad) return;
+  if (i < c) {
+    const float s = gamma[i] / sqrtf(var[i] + eps);
+    scale[i] = s;
+    shift[i] = beta[i] - mean[i] * s;
+  } else {
+    scale[i] = 0.f;
+    shift[i] = 0.f;
+  }
+}
+
+// w [Cout][Cin][kh][kw] (PyTorch) -> packed [Cout_pad][(ky*kw+kx)*Cin_pad + ci], optionally * scale[co]
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ scale, int cout,
+                                 int cin, int ks, int cout_pad, int cin_pad, float* __restrict__ out) {
+  const int kpad = ks * ks * cin_pad;
+  const size_t total = (size_t)cout_pad * kpad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / kpad);
+    const int r = (int)(i - (size_t)co * kpad);
+    const int tap = r / cin_pad;
+    const int ci = r - tap * cin_pad;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      v = w[((size_t)co * cin + ci) * ks * ks + tap];
+      if (scale) v *= scale[co];
+    }
+    out[i] = v;
+  }
+}
+
+// stem weights [Cout][1][7][7] -> [Cout][64] (k = ky*7+kx, zero padded), * scale[co]
+__global__ void pack_stem_kernel(const float* __restrict__ w, const float* __restrict__ scale, int cout,
+                                 float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * 64) return;
+  const int co = i >> 6, k = i & 63;
+  out[i] = k < 49 ? w[co * 49 + k] * scale[co] : 0.f;
+}
+
+// im2col of the 1-channel image for the 7x7 stride-2 pad-3 stem (resnet.py:101,143):
+// col[(b*Ho+oy)*Wo+ox][k] = img[b][2*oy+ky-3][2*ox+kx-3], k = ky*7+kx < 49, else 0.
+__global__ void stem_im2col_kernel(const float* __restrict__ img, int B, int H, int W, int Ho, int Wo,
+                                   float* __restrict__ col) {
+  const size_t total = (size_t)B * Ho * Wo * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i & 63);
+    const size_t p = i >> 6;
+    const int ox = (int)(p % Wo);
+    const size_t t = p / Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float v = 0.f;
+    if (k < 49) {
+      const int ky = k / 7, kx = k - ky * 7;
+      const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[((size_t)b * H + iy) * W + ix];
+    }
+    col[i] = v;
+  }
+}
+
+// out[i] = a[i] + b[i]   (float4 granularity; sizes multiple of 4)
+__global__ void add4_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = a[i], y = b[i];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+// generic 2D transpose in[R][Cc] -> out[Cc][R] through an LDS tile (used for layout conversion of
+// NCHW <-> NHWC test/interop buffers and the keypoint-MLP weights)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const size_t zoff = (size_t)blockIdx.z * R * Cc;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < R && c < Cc) ? in[zoff + (size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = bx + j, r = by + tx;
+    if (c < Cc && r < R) out[zoff + (size_t)c * R + r] = tile[tx][j];
+  }
+}
+
+}  // namespace
+
+int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                int c, int c_pad, float* scale, float* shift, hipStream_t stream) {
+  hipLaunchKernelGGL(fold_bn_kernel, dim3(opp_cdiv(c_pad, 256)), dim3(256), 0, stream, gamma, beta, mean, var, eps, c, c_pad, scale, shift);
+  OPP_CHECK_LAUNCH("fold_bn_kernel");
+  return OPP_OK;
+}
+
+int opp_pack_conv(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
+                  float* out, hipStream_t stream) {
+  const size_t total = (size_t)cout_pad * ks * ks * cin_pad;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, stream, w, scale, cout, cin, ks, cout_pad, cin_pad, out);
+  OPP_CHECK_LAUNCH("pack_conv_kernel");
+  return OPP_OK;
+}
+
+int opp_pack_stem(const float* w, const float* scale, int cout, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_stem_kernel, dim3(opp_cdiv(cout * 64, 256)), dim3(256), 0, stream, w, scale, cout, out);
+  OPP_CHECK_LAUNCH("pack_stem_kernel");
+  return OPP_OK;
+}
+
+int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream_t stream) {
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  const size_t total = (size_t)B * Ho * Wo * 64;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks), dim3(256), 0, stream, img, B, H, W, Ho, Wo, col);
+  OPP_CHECK_LAUNCH("stem_im2col_kernel");
+  return OPP_OK;
+}
+
+int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream) {
+  OPP_CHECK_ARG(n % 4 == 0, "add: n %% 4 != 0");
+  const size_t n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add4_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)a, (const float4*)b, (float4*)out, n4);
+  OPP_CHECK_LAUNCH("add4_kernel");
+  return OPP_OK;
+}
+
+int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(opp_cdiv(Cc, 32), opp_cdiv(R, 32), batch), dim3(256), 0, stream, in, out, R, Cc);
+  OPP_CHECK_LAUNCH("transpose_kernel");
+  return OPP_OK;
+}

@@ -1,0 +1,284 @@
+// Coarse matching: dual-softmax confidence matrix + mutual-nearest-neighbour selection.
+//
+// Reference: CoarseMatching.forward / get_coarse_match / mask_border
+//            src/models/OnePosePlus/utils/coarse_matching.py:10-20, :76-123, :125-242
+//
+// The similarity matrix S [N][L] (N 3D points x L = hc*wc image cells) is produced by the
+// score GEMM (gemm_mfma.hip, temperature scaling fused).  Everything here is HBM/L2-bound
+// row / column sweeps of that matrix:
+//   conf[i][j] = softmax_over_i(S)[i][j] * softmax_over_j(S)[i][j]        (:115)
+//   keep (i,j) if conf > thr, cell not in the first `border_rm` rows/cols (quirk q1),
+//   conf == rowmax_i(conf) and conf == colmax_j(conf)                      (:145-163)
+//   matches ordered by ascending i, first surviving j per row (quirk q9)   (:166-172)
+// All equality tests are done on the conf values this code itself wrote, so the decision is
+// self-consistent (SURVEY.md §7 "hard parts").
+#include "opp_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_add(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int VEC>
+struct Ld;
+template <>
+struct Ld<4> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <>
+struct Ld<1> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+
+// ---- per-row max and sum exp(s - max): one wave per row -----------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ S, int N, int L,
+                                                        float* __restrict__ rmax, float* __restrict__ rsum) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const float* s = S + (size_t)row * L;
+  float m = -INFINITY;
+  for (int j = lane * VEC; j < L; j += 64 * VEC) {
+    float v[VEC];
+    Ld<VEC>::load(s + j, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m = fmaxf(m, v[e]);
+  }
+  m = wave_max(m);
+  float acc = 0.f;
+  for (int j = lane * VEC; j < L; j += 64 * VEC) {
+    float v[VEC];
+    Ld<VEC>::load(s + j, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc += expf(v[e] - m);
+  }
+  acc = wave_add(acc);
+  if (lane == 0) {
+    rmax[row] = m;
+    rsum[row] = acc;
+  }
+}
+
+// ---- column sweeps: thread per column, block = 256 columns x one chunk of rows -------------
+// MODE 0: partial max ; MODE 1: partial sum exp(s - cmax[col])
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ S, int N, int L, int chunk_rows,
+                                                          const float* __restrict__ cmax, float* __restrict__ part) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= L) return;
+  const int r0 = blockIdx.y * chunk_rows;
+  const int r1 = min(N, r0 + chunk_rows);
+  float acc = MODE == 0 ? -INFINITY : 0.f;
+  const float cm = MODE == 1 ? cmax[col] : 0.f;
+  const float* p = S + (size_t)r0 * L + col;
+  for (int r = r0; r < r1; ++r, p += L) {
+    const float v = *p;
+    if (MODE == 0) acc = fmaxf(acc, v);
+    else acc += expf(v - cm);
+  }
+  part[(size_t)blockIdx.y * L + col] = acc;
+}
+
+template <int MODE>
+__global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, int L, float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= L) return;
+  float acc = MODE == 0 ? -INFINITY : 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float v = part[(size_t)c * L + col];
+    if (MODE == 0) acc = fmaxf(acc, v);
+    else acc += v;
+  }
+  out[col] = acc;
+}
+
+// ---- conf = colsoftmax * rowsoftmax, in place; per-row max / first argmax / tie count --------
+template <int VEC>
+__global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N, int L,
+                                                   const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                   const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                   float* __restrict__ row_cmax, int* __restrict__ row_arg,
+                                                   int* __restrict__ row_ties) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float* s = S + (size_t)row * L;
+  const float rm = rmax[row], rs = rsum[row];
+  float best = -1.f;
+  int arg = 0x7fffffff;
+  for (int j = lane * VEC; j < L; j += 64 * VEC) {
+    float v[VEC], cm[VEC], cs[VEC];
+    Ld<VEC>::load(s + j, v);
+    Ld<VEC>::load(cmax + j, cm);
+    Ld<VEC>::load(csum + j, cs);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
+      const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
+      const float c = pc * pr;
+      v[e] = c;
+      if (c > best) {
+        best = c;
+        arg = j + e;
+      }
+    }
+    Ld<VEC>::store(s + j, v);
+  }
+  // wave arg-max, ties to the lowest column
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oa = __shfl_xor(arg, o, 64);
+    if (ob > best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  int ties = 0;
+  for (int j = lane * VEC; j < L; j += 64 * VEC) {
+    float v[VEC];
+    Ld<VEC>::load(s + j, v);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) ties += (v[e] == best) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
+  if (lane == 0) {
+    row_cmax[row] = best;
+    row_arg[row] = arg;
+    row_ties[row] = ties;
+  }
+}
+
+// ---- selection + ordered compaction: single block ------------------------------------------
+__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ conf, int N, int L, int wc,
+                                                      const float* __restrict__ row_cmax, const int* __restrict__ row_arg,
+                                                      const int* __restrict__ row_ties, const float* __restrict__ col_cmax,
+                                                      float thr, int border, const float* __restrict__ kpts,
+                                                      float base_scale, const float* __restrict__ qscale,
+                                                      long long* __restrict__ i_ids, long long* __restrict__ j_ids,
+                                                      float* __restrict__ mconf, float* __restrict__ mkpts_c,
+                                                      float* __restrict__ mkpts_3d, int* __restrict__ count) {
+  __shared__ int wave_tot[16];
+  __shared__ int running;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) running = 0;
+  // scale * query_image_scale[b][[1, 0]]  (coarse_matching.py:223-228); (h_scale, w_scale) order
+  const float sx = qscale ? base_scale * qscale[1] : base_scale;
+  const float sy = qscale ? base_scale * qscale[0] : base_scale;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    int sel = -1;
+    float c = 0.f;
+    if (i < N) {
+      c = row_cmax[i];
+      if (c > thr) {
+        if (row_ties[i] == 1) {
+          const int j = row_arg[i];
+          const int jy = j / wc, jx = j - jy * wc;
+          if (jy >= border && jx >= border && c == col_cmax[j]) sel = j;
+        } else {  // exact ties inside the row (rare): first column that survives every test
+          const float* r = conf + (size_t)i * L;
+          for (int j = 0; j < L; ++j) {
+            if (r[j] == c && c == col_cmax[j]) {
+              const int jy = j / wc, jx = j - jy * wc;
+              if (jy >= border && jx >= border) {
+                sel = j;
+                break;
+              }
+            }
+          }
+        }
+      }
+    }
+    const int flag = sel >= 0 ? 1 : 0;
+    // block exclusive scan of flags
+    const unsigned long long bal = __ballot(flag);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (flag) {
+      const int m = off + before;
+      i_ids[m] = i;
+      j_ids[m] = sel;
+      mconf[m] = c;
+      const int jy = sel / wc, jx = sel - jy * wc;
+      mkpts_c[2 * m + 0] = (float)jx * sx;
+      mkpts_c[2 * m + 1] = (float)jy * sy;
+      mkpts_3d[3 * m + 0] = kpts[3 * i + 0];
+      mkpts_3d[3 * m + 1] = kpts[3 * i + 1];
+      mkpts_3d[3 * m + 2] = kpts[3 * i + 2];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+      running += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *count = running;
+}
+
+}  // namespace
+
+size_t opp_coarse_match_scratch_floats(int N, int L) {
+  const int chunks = opp_cdiv(N, 128);
+  const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
+  // rmax, rsum, row_cmax [Np] ; row_arg, row_ties [Np] (int) ; cmax, csum, col_cmax [Lp] ; partials [chunks][L]
+  return 5 * Np + 3 * Lp + (size_t)chunks * L + 64;
+}
+
+// S (in: similarity, out: confidence matrix) [N][L].  Outputs have capacity N.
+int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts, float base_scale,
+                            const float* qscale, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
+                            float* mkpts_3d, int* count, hipStream_t stream) {
+  OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0, "coarse match: bad sizes N=%d L=%d wc=%d", N, L, wc);
+  const int chunks = opp_cdiv(N, 128);
+  const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
+  float* rmax = scratch;
+  float* rsum = rmax + Np;
+  float* row_cmax = rsum + Np;
+  int* row_arg = reinterpret_cast<int*>(row_cmax + Np);
+  int* row_ties = row_arg + Np;
+  float* cmax = reinterpret_cast<float*>(row_ties + Np);
+  float* csum = cmax + Lp;
+  float* col_cmax = csum + Lp;
+  float* part = col_cmax + Lp;
+  const bool vec4 = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cmax) & 15) == 0);
+  dim3 rgrid(opp_cdiv(N, 4)), cgrid(opp_cdiv(L, 256), chunks), lgrid(opp_cdiv(L, 256));
+
+  if (vec4) hipLaunchKernelGGL(row_stats_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
+  else hipLaunchKernelGGL(row_stats_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
+  hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
+  hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, cmax);
+  hipLaunchKernelGGL(col_partial_kernel<1>, cgrid, dim3(256), 0, stream, S, N, L, 128, cmax, part);
+  hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum);
+  if (vec4) hipLaunchKernelGGL(conf_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
+  else hipLaunchKernelGGL(conf_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
+  hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
+  hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax);
+  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, S, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr,
+                     border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
+  OPP_CHECK_LAUNCH("coarse match kernels");
+  return OPP_OK;
+}

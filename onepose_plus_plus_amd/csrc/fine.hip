@@ -1,0 +1,116 @@
+// Fine stage: 5x5 window gather at 1/2 resolution (no unfold materialisation) and the
+// sub-pixel expectation head.
+//
+// Reference:
+//   FinePreprocess._forward  src/models/OnePosePlus/loftr_module/fine_preprocess.py:41-55
+//   FineMatching             src/models/OnePosePlus/utils/fine_matching.py:28-110
+//   kornia 0.4.1 dsnt.spatial_expectation2d / create_meshgrid (normalised {-1..1} grid, x fastest)
+//
+// The gather is HBM-bound: M * W*W * C * 4 bytes (12.8 KB per match) read from the NHWC fine
+// feature map with lanes along the channel axis (512 B contiguous per window cell).
+#include "opp_common.h"
+
+namespace {
+
+// win [M][WW][C] (token-major: M*WW rows of C) ; f3 [M][C] ; feat NHWC [Hf][Wf][ldf] ; bank [C][N]
+__global__ __launch_bounds__(128) void fine_gather_kernel(const float* __restrict__ feat, int Hf, int Wf, int ldf,
+                                                          const float* __restrict__ bank, int n_points,
+                                                          const long long* __restrict__ i_ids,
+                                                          const long long* __restrict__ j_ids, int wc, int stride,
+                                                          int Wwin, int C, float* __restrict__ win, int ldw,
+                                                          float* __restrict__ f3, int ld3) {
+  const int m = blockIdx.x;
+  const int j = (int)j_ids[m];
+  const int jy = j / wc, jx = j - jy * wc;
+  const int cy = jy * stride - Wwin / 2, cx = jx * stride - Wwin / 2;
+  const int WW = Wwin * Wwin;
+  for (int e = threadIdx.x; e < WW * C; e += blockDim.x) {
+    const int r = e / C, c = e - r * C;
+    const int ky = r / Wwin, kx = r - ky * Wwin;
+    const int y = cy + ky, x = cx + kx;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf) v = feat[((size_t)y * Wf + x) * ldf + c];
+    win[((size_t)m * WW + r) * ldw + c] = v;
+  }
+  const long long i = i_ids[m];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) f3[(size_t)m * ld3 + c] = bank[(size_t)c * n_points + i];
+}
+
+// one wave per match: heatmap = softmax(<f3, win_r> / sqrt(C)) over WW cells; expectation + std
+__global__ __launch_bounds__(256) void fine_head_kernel(const float* __restrict__ f3, int ld3,
+                                                        const float* __restrict__ win, int ldw, int M, int Wwin,
+                                                        int C, float temp, const float* __restrict__ mkpts_c, float base_scale,
+                                                        const float* __restrict__ qscale,
+                                                        float* __restrict__ expec, float* __restrict__ mkpts_f) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int WW = Wwin * Wwin;   // <= 64 handled by one lane per cell
+  float sim = -INFINITY;
+  if (lane < WW) {
+    const float* w = win + ((size_t)m * WW + lane) * ldw;
+    const float* f = f3 + (size_t)m * ld3;
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(f[c], w[c], acc);
+    sim = temp * acc;   // softmax_temp * sim_matrix, fine_matching.py:82-83
+  }
+  float mx = sim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float e = lane < WW ? expf(sim - mx) : 0.f;
+  float tot = e;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  const float p = e / tot;
+  // normalised grid: (k / (W-1) - 0.5) * 2, x fastest
+  float gx = 0.f, gy = 0.f;
+  if (lane < WW) {
+    const int ky = lane / Wwin, kx = lane - ky * Wwin;
+    gx = ((float)kx / (float)(Wwin - 1) - 0.5f) * 2.f;
+    gy = ((float)ky / (float)(Wwin - 1) - 0.5f) * 2.f;
+  }
+  float ex = gx * p, ey = gy * p, exx = gx * gx * p, eyy = gy * gy * p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ex += __shfl_xor(ex, o, 64);
+    ey += __shfl_xor(ey, o, 64);
+    exx += __shfl_xor(exx, o, 64);
+    eyy += __shfl_xor(eyy, o, 64);
+  }
+  if (lane == 0) {
+    const float vx = fmaxf(exx - ex * ex, 1e-10f);
+    const float vy = fmaxf(eyy - ey * ey, 1e-10f);
+    expec[3 * m + 0] = ex;
+    expec[3 * m + 1] = ey;
+    expec[3 * m + 2] = sqrtf(vx) + sqrtf(vy);
+    const float half_w = (float)(Wwin / 2);
+    // scale * query_image_scale[b][[1, 0]]  (fine_matching.py:104)
+    const float qsx = qscale ? base_scale * qscale[1] : base_scale;
+    const float qsy = qscale ? base_scale * qscale[0] : base_scale;
+    mkpts_f[2 * m + 0] = mkpts_c[2 * m + 0] + (ex * half_w) * qsx;
+    mkpts_f[2 * m + 1] = mkpts_c[2 * m + 1] + (ey * half_w) * qsy;
+  }
+}
+
+}  // namespace
+
+int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,
+                    const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,
+                    float* win, int ldw, float* f3, int ld3, hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  hipLaunchKernelGGL(fine_gather_kernel, dim3(M), dim3(128), 0, stream, feat, Hf, Wf, ldf, bank, n_points, i_ids, j_ids, wc,
+                     stride, Wwin, C, win, ldw, f3, ld3);
+  OPP_CHECK_LAUNCH("fine_gather_kernel");
+  return OPP_OK;
+}
+
+int opp_fine_head(const float* f3, int ld3, const float* win, int ldw, int M, int Wwin, int C, float temp,
+                  const float* mkpts_c, float base_scale, const float* qscale, float* expec, float* mkpts_f,
+                  hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(Wwin * Wwin <= 64, "fine head: window %d too large", Wwin);
+  hipLaunchKernelGGL(fine_head_kernel, dim3(opp_cdiv(M, 4)), dim3(256), 0, stream, f3, ld3, win, ldw, M, Wwin, C, temp, mkpts_c,
+                     base_scale, qscale, expec, mkpts_f);
+  OPP_CHECK_LAUNCH("fine_head_kernel");
+  return OPP_OK;
+}

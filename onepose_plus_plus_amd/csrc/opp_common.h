@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels of the OnePose++
+// 2D-3D matching hot path.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define OPP_OK 0
+#define OPP_ERR_INVALID (-1)
+#define OPP_ERR_UNSUPPORTED (-2)
+#define OPP_ERR_LAUNCH (-3)
+#define OPP_ERR_WORKSPACE (-4)
+
+void opp_set_error(const char* fmt, ...);
+
+#define OPP_CHECK_ARG(cond, ...)                  \
+  do {                                            \
+    if (!(cond)) {                                \
+      opp_set_error(__VA_ARGS__);                 \
+      return OPP_ERR_INVALID;                     \
+    }                                             \
+  } while (0)
+
+#define OPP_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      opp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return OPP_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+#define OPP_TRY(expr)            \
+  do {                           \
+    int rc__ = (expr);           \
+    if (rc__ != OPP_OK) return rc__; \
+  } while (0)
+
+static inline int opp_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t opp_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   C[m][n] = epilogue( sum_k A[m][k] * W[n][k] )        ("TN": both operands K-contiguous)
+// A is either a dense row-major matrix (optionally the concatenation [A0 | A1] along K) or
+// the implicit im2col view of an NHWC activation tensor (3x3 / 1x1, stride 1 / 2).
+// ---------------------------------------------------------------------------------------
+enum { OPP_ACT_NONE = 0, OPP_ACT_RELU = 1, OPP_ACT_LEAKY = 2, OPP_ACT_QKV = 3 };
+enum { OPP_RES_NONE = 0, OPP_RES_DIRECT = 1, OPP_RES_BILINEAR2X = 2 };
+
+struct OppGemm {
+  // A operand -- dense mode
+  const float* A0 = nullptr;
+  const float* A1 = nullptr;
+  int ksplit = 0;  // k <  ksplit -> A0[row*lda0 + k] ; k >= ksplit -> A1[row*lda1 + k-ksplit]
+  int lda0 = 0, lda1 = 0;
+  // A operand -- conv mode (A0 = NHWC input [B][Hin][Win][Cin], Cin % 32 == 0)
+  int conv = 0;
+  int Bn = 1, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, ksize = 1, stride = 1, pad = 0;
+  // B operand: weights [N][K] row-major (row stride ldw)
+  const float* W = nullptr;
+  int ldw = 0;
+  int M = 0, N = 0, K = 0;  // K % 32 == 0 ; rows >= N of W are treated as zero
+  // output
+  float* C = nullptr;
+  int ldc = 0;
+  int n_store = 0;  // columns [0, n_store) are written (n_store >= N pads with act(0))
+  const float* bias = nullptr;  // [n_store] or null
+  // residual added before the activation
+  int res_mode = OPP_RES_NONE;
+  const float* R = nullptr;
+  int ldr = 0, Hr = 0, Wr = 0;
+  float res_sy = 0.f, res_sx = 0.f;
+  // activation
+  int act = OPP_ACT_NONE;
+  int qk_cols = 0;     // OPP_ACT_QKV: columns < qk_cols get elu(x)+1, the rest x / seg_len(row)
+  int split_row = 0;   // rows < split_row divide by s0, others by s1
+  float s0 = 1.f, s1 = 1.f;
+  // generic output scaling: y = acc * out_mul / out_div (applied first; used by the score GEMM)
+  float out_mul = 1.f, out_div = 1.f;
+  // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
+  double alg_flops = 0.0;
+};
+
+int opp_gemm_launch(const OppGemm& g, hipStream_t stream);
+// picks a tile configuration; exposed for tests / tuning (cfg < 0 = automatic)
+int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream);

@@ -1,0 +1,38 @@
+// Internal (non-exported) launchers shared between the .hip translation units.
+#pragma once
+#include "opp_common.h"
+
+// attention.hip
+int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res, int ldres,
+                  float* out, int ldo, int rows, int C, float eps, hipStream_t stream);
+int opp_linattn_chunks(int seg_len);
+int opp_linattn_kv(const float* k, const float* v, int ld, int n_seg, int seg_len, int C, int D, float* kv_out,
+                   float* ks_out, float* scratch, hipStream_t stream);
+int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks, float* out, int ldo, int n_seg,
+                      int seg_len, int src_len, int C, int D, float eps, hipStream_t stream);
+// backbone.hip
+int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
+                int c_pad, float* scale, float* shift, hipStream_t stream);
+int opp_pack_conv(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
+                  float* out, hipStream_t stream);
+int opp_pack_stem(const float* w, const float* scale, int cout, float* out, hipStream_t stream);
+int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream_t stream);
+int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
+int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream);
+// kpt.hip
+int opp_kpt_stats(const float* kpts, int n, float* stats, hipStream_t stream);
+int opp_kpt_encode(const float* kpts, const float* stats, const float* bank, int n, const float* const* wt,
+                   const float* const* bias, float* tokens, int ldo, hipStream_t stream);
+int opp_bank_transpose(const float* bank, int n, int C, float* tokens, int ldo, hipStream_t stream);
+// coarse_match.hip
+size_t opp_coarse_match_scratch_floats(int N, int L);
+int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts,
+                            float base_scale, const float* qscale, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                            float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);
+// fine.hip
+int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,
+                    const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,
+                    float* win, int ldw, float* f3, int ld3, hipStream_t stream);
+int opp_fine_head(const float* f3, int ld3, const float* win, int ldw, int M, int Wwin, int C, float temp,
+                  const float* mkpts_c, float base_scale, const float* qscale, float* expec, float* mkpts_f,
+                  hipStream_t stream);

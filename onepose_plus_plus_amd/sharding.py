@@ -1,0 +1,86 @@
+"""Per-object sharding of the matching forward across the GPUs of one node.
+
+Replaces the reference's Ray fan-out (src/utils/ray_utils.py:10-110,
+src/inference/inference_OnePosePlus.py:62-99, inference.py:83-106): one process per GPU
+(`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests),
+objects -> ranks, ONE broadcast of the weights at start-up, no collective in the data path,
+results gathered on the host at the end.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_objects(objects, rank, world_size):
+    """Objects are independent (inference.py:137-191 loops over them); rank r takes every
+    world_size-th object starting at r, which balances clouds of different size on average."""
+    return list(objects)[rank::world_size]
+
+
+def chunk_index(n_items, n_chunks):
+    """Contiguous index chunks, sizes differing by at most 1 (the split the reference uses for
+    image subsets, src/utils/ray_utils.py:95-103 semantics: every item exactly once)."""
+    base, rem = divmod(n_items, n_chunks)
+    out, start = [], 0
+    for i in range(n_chunks):
+        size = base + (1 if i < rem else 0)
+        out.append(list(range(start, start + size)))
+        start += size
+    return out
+
+
+def broadcast_weights(model, state_dict=None, src=0, group=None):
+    """Rank `src` holds `state_dict`; every rank ends with it loaded (strict).  The float
+    tensors travel as ONE flat fp32 buffer (40.9 MB for the shipped config: a single RCCL
+    broadcast over xGMI); integer counters (num_batches_tracked) as one int64 buffer."""
+    rank = dist.get_rank(group)
+    ref = model.state_dict()
+    device = next(model.parameters()).device
+    fkeys = [k for k, v in ref.items() if v.is_floating_point()]
+    ikeys = [k for k, v in ref.items() if not v.is_floating_point()]
+    fbuf = torch.empty(sum(ref[k].numel() for k in fkeys), dtype=torch.float32, device=device)
+    ibuf = torch.empty(len(ikeys), dtype=torch.int64, device=device)
+    if rank == src:
+        if state_dict is None:
+            raise ValueError("source rank needs the state dict")
+        missing = [k for k in ref if k not in state_dict]
+        if missing:
+            raise KeyError("state dict is missing %s" % missing[:3])
+        fbuf.copy_(torch.cat([state_dict[k].reshape(-1).float() for k in fkeys]).to(device))
+        if ikeys:
+            ibuf.copy_(torch.stack([state_dict[k].reshape(()).long() for k in ikeys]).to(device))
+    dist.broadcast(fbuf, src=src, group=group)
+    if ikeys:
+        dist.broadcast(ibuf, src=src, group=group)
+    out, off = {}, 0
+    for k in fkeys:
+        n = ref[k].numel()
+        out[k] = fbuf[off:off + n].view(ref[k].shape)
+        off += n
+    for i, k in enumerate(ikeys):
+        out[k] = ibuf[i].clone()
+    model.load_state_dict(out, strict=True)
+    return model
+
+
+def gather_results(local_results, dst=0, group=None):
+    """Host-side gather of per-object results (small python objects: ids, confidences, poses)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    bucket = [None] * world if rank == dst else None
+    dist.gather_object(local_results, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return merged
+
+
+def run_sharded(objects, forward_fn, group=None, dst=0):
+    """objects: {name: payload}.  Each rank runs forward_fn(name, payload) on its shard; rank
+    `dst` receives {name: result} for every object."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    names = sorted(objects)
+    mine = shard_objects(names, rank, world)
+    local = {n: forward_fn(n, objects[n]) for n in mine}
+    return gather_results(local, dst=dst, group=group)

@@ -1,0 +1,88 @@
+"""GPU: whole `OnePosePlus_model(data)` forward through the HIP path against (a) the golden
+vectors produced by the upstream reference and (b) the CPU oracle, plus size-independent
+properties at BASELINE sizes (512x512 x 5k / 15k points)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden.cases import E2E_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(E2E_CASES))
+def test_e2e_vs_golden(name):
+    from tests import hip_ops as ops
+    cfg, sd, data = H.e2e_setup(name)
+    model = ops.make_model(cfg, sd)
+    out = ops.run_model(model, data)
+    gold = H.load_golden(name)
+    H.assert_match_outputs(out, gold, where=name)
+    meta = gold["meta"]
+    assert out["bs"] == meta[0] and tuple(out["q_hw_i"]) == tuple(meta[1:3])
+    assert tuple(out["q_hw_c"]) == tuple(meta[3:5]) and tuple(out["q_hw_f"]) == tuple(meta[5:7])
+    for k in ("i_ids", "j_ids", "b_ids", "m_bids"):
+        assert out[k].dtype == torch.int64 and out[k].is_cuda
+    assert out["gt_mask"].dtype == torch.bool
+    assert out["conf_matrix"].shape == (1, data["keypoints3d"].shape[1], meta[3] * meta[4])
+    if cfg["fine_matching"]["enable"]:
+        assert out["W"] == meta[7]
+        assert out["expec_f"].shape == (len(gold["mconf"]), 3)
+    assert out["mkpts_query_f"].shape == (len(gold["mconf"]), 2)
+
+
+def test_e2e_vs_oracle_and_determinism():
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    cfg, sd, data = H.e2e_setup("e2e_128x128_n300_thr0")
+    model = ops.make_model(cfg, sd)
+    out1 = ops.run_model(model, data)
+    out2 = ops.run_model(model, data)
+    for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+        assert torch.equal(out1[k], out2[k]), k            # bit-reproducible run to run
+    ref = {k: v.clone() for k, v in data.items()}
+    O.forward(sd, ref, cfg)
+    gold = {k: H.to_np(ref[k]) for k in ("i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f", "mkpts_query_c")}
+    gold.update(H.conf_digest_t(ref["conf_matrix"]))
+    H.assert_match_outputs(out1, gold, where="oracle")
+    # input tensors are not modified (ownership contract)
+    fresh = H.e2e_setup("e2e_128x128_n300_thr0")[2]
+    for k, v in fresh.items():
+        assert torch.equal(v, data[k]), k
+
+
+@pytest.mark.parametrize("n", [5000, 15000])
+def test_full_size_properties(n):
+    """BASELINE sizes: properties that hold for any input (no oracle needed)."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    from onepose_plus_plus_amd.config import default_config
+    cfg = default_config(thr=0.0)
+    model = ops.make_model(cfg, make_state_dict(cfg, 0))
+    out = ops.run_model(model, make_inputs(n, (512, 512), 1))
+    conf = out["conf_matrix"][0]
+    assert torch.isfinite(conf).all() and (conf >= 0).all()
+    assert conf.sum(1).max() <= 1 + 1e-4 and conf.sum(0).max() <= 1 + 1e-4      # product of two softmaxes
+    i, j, c = out["i_ids"], out["j_ids"], out["mconf"]
+    assert (i[1:] > i[:-1]).all()                                                   # ascending, unique 3D ids
+    assert len(torch.unique(j)) == len(j)                                           # mutual NN: unique cells
+    assert torch.equal(c, conf[i, j])
+    assert torch.equal(c, conf.max(1).values[i]) and torch.equal(c, conf.max(0).values[j])
+    jy, jx = j // 64, j % 64
+    assert (jy >= 2).all() and (jx >= 2).all()                                      # border quirk q1
+    # every mutual-NN pair above thr outside the border is reported (completeness)
+    rmax, rarg = conf.max(1)
+    cmax = conf.max(0).values
+    ok = (rmax > 0.0) & (rmax == cmax[rarg]) & (rarg // 64 >= 2) & (rarg % 64 >= 2)
+    assert int(ok.sum()) == len(i)
+    ex = out["expec_f"]
+    assert ex.shape == (len(i), 3) and (ex[:, :2].abs() <= 1).all() and (ex[:, 2] > 0).all()
+    assert (out["mkpts_query_f"] - out["mkpts_query_c"]).abs().max() <= 2.0 * 2 + 1e-3
+
+
+def test_no_cpu_fallback():
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    m = OnePosePlus_model(default_config()).eval()
+    with pytest.raises(RuntimeError):
+        m({"query_image": torch.zeros(1, 1, 64, 64)})

@@ -1,0 +1,115 @@
+"""GPU: building-block kernels (fp32 MFMA GEMM / implicit-GEMM conv, LayerNorm) against a
+float64 CPU evaluation of the same op.  Called through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bound(A, W):
+    return (A.abs().double() @ W.abs().double().T).float()
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (1000, 64, 128), (77, 256, 96)])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+def test_linear_tiles(M, K, N, cfg):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)   # asymmetric: catches transposed operands / outputs
+    ref = (A.double() @ W.double().T).float()
+    got = ops.linear(A, W, 0, cfg)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert (err <= 2e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
+
+
+@pytest.mark.parametrize("cfg", [3, 4, -1])
+@pytest.mark.parametrize("N", [224, 448])
+def test_linear_224_tiles(cfg, N):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(N)
+    A = torch.randn(333, 96, generator=g)
+    W = torch.randn(N, 96, generator=g)
+    ref = (A.double() @ W.double().T).float()
+    got = ops.linear(A, W, 1, cfg)
+    assert ((got - ref.clamp(min=0)).abs() <= 2e-6 * _bound(A, W) + 1e-6).all()
+
+
+def test_linear_identity_layout():
+    """A = I with an asymmetric W: output must equal W^T exactly (row/col swap detector)."""
+    from tests import hip_ops as ops
+    W = torch.arange(128 * 64, dtype=torch.float32).reshape(128, 64) / 7.0
+    A = torch.eye(64)
+    got = ops.linear(A, W, 0, -1)
+    assert torch.equal(got, W.T.contiguous())
+
+
+CONV_CASES = [
+    # cin, cout, ks, stride, H, W
+    (128, 128, 3, 1, 24, 40),
+    (128, 196, 3, 2, 24, 40),
+    (196, 196, 3, 1, 16, 24),
+    (128, 196, 1, 2, 24, 40),
+    (196, 256, 1, 1, 16, 24),
+    (256, 196, 3, 1, 10, 12),
+    (256, 256, 3, 1, 8, 8),
+]
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
+@pytest.mark.parametrize("cfg", [-1, 0, 2])
+def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
+    from tests import hip_ops as ops
+    if cout == 196 and cfg != -1:
+        cfg = 3 if cfg == 0 else 4
+    g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+    res = torch.randn(1, cout, Ho, Wo, generator=g)
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride, ks // 2) + res.double()
+    ref = F.relu(ref).float()
+    got, pad_max = ops.conv2d(x, w, scale, bias, stride, res, 1, 1, cfg)
+    assert pad_max == 0.0          # padded channels must stay exactly zero
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(196, 256, 12, 16), (128, 196, 20, 12)])
+def test_conv1x1_bilinear_residual(cin, cout, H, W):
+    """lateral 1x1 conv + align_corners=True x2 upsample of the coarser map (resnet.py:151-157)."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    low = torch.randn(1, cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x, w) + F.interpolate(low, scale_factor=2.0, mode="bilinear", align_corners=True)
+    got, pad_max = ops.conv2d(x, w, None, None, 1, low, 2, 0, -1)
+    assert pad_max == 0.0
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv_leaky():
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 128, 9, 11, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None, 1, 1), 0.01).float()
+    got, _ = ops.conv2d(x, w, None, None, 1, None, 0, 2, -1)
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_layernorm(C):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(517, C, generator=g) * 3 + 1
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    res = torch.randn(517, C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    assert (ops.layer_norm(x, gam, bet) - ref.float()).abs().max() < 2e-5
+    assert (ops.layer_norm(x, gam, bet, res) - (res.double() + ref).float()).abs().max() < 2e-5

@@ -1,0 +1,95 @@
+"""GPU: each stage of the hot path (C ABI) against the CPU oracle / the reference golden
+vectors on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden.cases import MATCHER_CASES, FINE_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def small():
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    cfg, sd, data = H.e2e_setup("e2e_128x128_n300_thr0")
+    model = ops.make_model(cfg, sd)
+    with torch.no_grad():
+        st = O.backbone_forward(sd, data["query_image"], stages=True)
+    return cfg, sd, data, model, st
+
+
+def test_backbone_small(small):
+    from tests import hip_ops as ops
+    cfg, sd, data, model, st = small
+    fc, ff = ops.backbone(model, data["query_image"])
+    assert torch.isfinite(fc).all() and torch.isfinite(ff).all()
+    assert _rel(fc, st["x3_out"]) < 2e-5, _rel(fc, st["x3_out"])
+    assert _rel(ff, st["x1_out"]) < 2e-5, _rel(ff, st["x1_out"])
+    gold = H.load_golden("stages_128x128_n300")
+    assert np.abs(fc.numpy() - gold["feat_c"]).max() < 5e-5 * max(1.0, np.abs(gold["feat_c"]).max())
+    assert np.abs(ff[:, :, ::4, ::4].numpy() - gold["feat_f"]).max() < 5e-5 * max(1.0, np.abs(gold["feat_f"]).max())
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (96, 64), (8, 8), (512, 512)])
+def test_backbone_shapes(small, hw):
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    cfg, sd, _, model, _ = small
+    g = torch.Generator().manual_seed(hw[0] * 31 + hw[1])
+    img = torch.rand(1, 1, hw[0], hw[1], generator=g)
+    with torch.no_grad():
+        rc, rf = O.backbone_forward(sd, img)
+    fc, ff = ops.backbone(model, img)
+    assert _rel(fc, rc) < 2e-5 and _rel(ff, rf) < 2e-5, (_rel(fc, rc), _rel(ff, rf))
+
+
+def test_tokens_and_transformer(small):
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    cfg, sd, data, model, st = small
+    gold = H.load_golden("stages_128x128_n300")
+    feat_c = torch.from_numpy(gold["feat_c"])
+    hc, wc = feat_c.shape[2:]
+    pe = O.sine_position_table(256, (256, 256))[0, :, :hc, :wc].permute(1, 2, 0).reshape(hc * wc, 256)
+    tok = ops.coarse_tokens(model, feat_c, pe, data["keypoints3d"], data["descriptors3d_coarse_db"])
+    L = hc * wc
+    assert np.abs(tok[:L].numpy() - gold["tokens2d"][0]).max() < 1e-5
+    ref3 = torch.from_numpy(gold["bank_enc"])[0].T
+    assert (tok[L:] - ref3).abs().max() < 3e-5, (tok[L:] - ref3).abs().max()
+    # transformer on the reference's own tokens
+    X = torch.cat([torch.from_numpy(gold["tokens2d"][0]), ref3], 0)
+    out = ops.transformer(model, 0, X, 1, L, ref3.shape[0])
+    assert _rel(out[:L], torch.from_numpy(gold["f2"][0])) < 5e-5
+    assert _rel(out[L:], torch.from_numpy(gold["f3"][0])) < 5e-5
+
+
+@pytest.mark.parametrize("name", list(MATCHER_CASES))
+def test_matcher_vs_golden(small, name):
+    from tests import hip_ops as ops
+    _, _, _, model0, _ = small
+    cfg, f3d, f2d, data = H.matcher_setup(name)
+    got = ops.coarse_match(model0, f3d[0], f2d[0], tuple(data["q_hw_c"]), data["keypoints3d"][0], 8.0,
+                           data["query_image_scale"][0])
+    gold = H.load_golden(name)
+    H.assert_match_outputs(got, gold, where=name)
+    c = got["conf_matrix"][0]
+    assert (c >= 0).all() and c.sum(1).max() <= 1 + 1e-4 and c.sum(0).max() <= 1 + 1e-4
+
+
+@pytest.mark.parametrize("name", list(FINE_CASES))
+def test_fine_vs_golden(small, name):
+    from tests import hip_ops as ops
+    _, _, _, model0, _ = small
+    cfg, sd, feat_f, bank_f, data = H.fine_setup(name)
+    ex, mf = ops.fine(model0, feat_f, bank_f, data["i_ids"], data["j_ids"], tuple(data["q_hw_c"]),
+                      data["mkpts_query_c"], 2.0, data["query_image_scale"][0])
+    gold = H.load_golden(name)
+    H.assert_match_outputs({"expec_f": ex, "mkpts_query_f": mf}, {k: gold[k] for k in ("expec_f", "mkpts_query_f")},
+                           where=name)
