@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library loads and exports every symbol include/opp_hip.h declares (no
+compute calls without a GPU); handle/queries that do not touch the device work."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "opp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(opp_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from onepose_plus_plus_amd.build import build
+    from onepose_plus_plus_amd import _lib
+    build(verbose=False)
+    return _lib.load()
+
+
+def test_exports_every_declared_symbol(lib):
+    from onepose_plus_plus_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 24
+    for s in syms:
+        assert hasattr(lib, s), "libopp_hip.so does not export %s" % s
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+
+
+def test_no_torch_types_in_abi():
+    src = open(os.path.join(ROOT, "include", "opp_hip.h")).read()
+    assert "torch" not in src.lower().replace("pytorch", "") and "at::" not in src and "#include <hip" not in src
+
+
+def test_handle_and_weight_table(lib):
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd.params import param_spec
+    cfg = default_config()
+    m = OnePosePlus_model(cfg)
+    ctx = ctypes.c_void_p()
+    ccfg = m._c_config()
+    assert lib.opp_create(ctypes.byref(ccfg), ctypes.byref(ctx)) == 0, lib.opp_last_error()
+    names = [lib.opp_weight_name(ctx, i).decode() for i in range(lib.opp_num_weights(ctx))]
+    spec = [(k, s) for k, s, kind in param_spec(cfg) if kind != "bn_count"]
+    assert names == [k for k, _ in spec]                      # reference state-dict order
+    for i, (k, s) in enumerate(spec):
+        n = 1
+        for d in s:
+            n *= d
+        assert lib.opp_weight_numel(ctx, i) == n, k
+    assert lib.opp_packed_weights_bytes(ctx) > 40e6          # 10.2 M params + channel padding
+    ws = lib.opp_forward_coarse_workspace_bytes(ctx, 512, 512, 5000)
+    assert 100e6 < ws < 2e9
+    assert lib.opp_fine_workspace_bytes(ctx, 0) > 0
+    lib.opp_destroy(ctx)
+
+
+def test_create_rejects_unsupported_config(lib):
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    m = OnePosePlus_model(default_config())
+    ccfg = m._c_config()
+    ccfg.coarse_d_model = 192
+    ctx = ctypes.c_void_p()
+    assert lib.opp_create(ctypes.byref(ccfg), ctypes.byref(ctx)) != 0
+    assert b"d_model" in lib.opp_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from onepose_plus_plus_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.OppError):
+        _lib.load()

@@ -1,0 +1,117 @@
+"""CPU: host-side mirror of the reference module API (construction, state-dict contract,
+pickling, error behaviour) -- no device work."""
+import pickle
+
+import pytest
+import torch
+
+from onepose_plus_plus_amd import OnePosePlus_model, default_config
+from onepose_plus_plus_amd.synthetic import make_state_dict
+from oracle.refload import reference_available, load_reference_model_class
+
+
+def test_state_dict_contract():
+    cfg = default_config()
+    m = OnePosePlus_model(cfg)
+    sd = m.state_dict()
+    assert len(sd) == 195
+    assert sum(v.numel() for k, v in sd.items() if "num_batches_tracked" not in k) == 10233184 - 0
+    assert "dense_pos_encoding.pe" not in sd               # non-persistent buffer
+    assert m.dense_pos_encoding.pe.shape == (1, 256, 256, 256)
+    gold = make_state_dict(cfg, 0)
+    assert list(sd.keys()) == list(gold.keys())
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(gold[k].shape), k
+    m.load_state_dict(gold, strict=True)
+    # checkpoint convention of the caller: strip 'matcher.' (inference_OnePosePlus.py:32-36)
+    ckpt = {"matcher." + k: v for k, v in gold.items()}
+    stripped = {k.replace("matcher.", ""): v for k, v in ckpt.items()}
+    OnePosePlus_model(cfg).load_state_dict(stripped, strict=True)
+    with pytest.raises(RuntimeError):
+        OnePosePlus_model(cfg).load_state_dict({k: v for k, v in list(gold.items())[:-1]}, strict=True)
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted")
+def test_state_dict_matches_live_reference():
+    cfg = default_config()
+    ref = load_reference_model_class()(cfg)
+    ours = OnePosePlus_model(cfg)
+    rs, os_ = ref.state_dict(), ours.state_dict()
+    assert list(rs.keys()) == list(os_.keys())
+    assert all(rs[k].shape == os_[k].shape and rs[k].dtype == os_[k].dtype for k in rs)
+    ours.load_state_dict(rs, strict=True)
+    ref.load_state_dict(os_, strict=True)
+    assert torch.equal(ref.dense_pos_encoding.pe, ours.dense_pos_encoding.pe)
+
+
+def test_pickle_roundtrip():
+    """Ray pickles the module into its workers (inference_OnePosePlus.py:85-95)."""
+    cfg = default_config()
+    m = OnePosePlus_model(cfg).eval()
+    m.load_state_dict(make_state_dict(cfg, 0))
+    m2 = pickle.loads(pickle.dumps(m))
+    assert not m2.training
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert m2._rt["ctx"] is None and m2._rt["dirty"]
+
+
+def test_pretrained_backbone_loading(tmp_path):
+    """OnePosePlusModel.py:78-94: keys containing 'backbone' are stripped and strict-loaded."""
+    cfg = default_config()
+    gold = make_state_dict(cfg, 5)
+    ck = {"matcher.backbone." + k[len("backbone."):]: v for k, v in gold.items() if k.startswith("backbone.")}
+    ck["matcher.loftr_coarse.layers.0.q_proj.weight"] = torch.zeros(1)    # must be ignored
+    path = tmp_path / "loftr.ckpt"
+    torch.save({"state_dict": ck}, path)
+    cfg["loftr_backbone"]["pretrained"] = str(path)
+    cfg["loftr_backbone"]["pretrained_fix"] = True
+    m = OnePosePlus_model(cfg)
+    assert torch.equal(m.backbone.conv1.weight, gold["backbone.conv1.weight"])
+    assert not any(p.requires_grad for p in m.backbone.parameters())
+    assert all(p.requires_grad for p in m.loftr_coarse.parameters())
+
+
+def test_unsupported_config_values_raise_like_reference():
+    cfg = default_config()
+    cfg["loftr_backbone"]["resolution"] = [16, 4]
+    with pytest.raises(NotImplementedError):          # backbone/__init__.py:9-12
+        OnePosePlus_model(cfg)
+    cfg = default_config()
+    cfg["loftr_backbone"]["type"] = "VGG"
+    with pytest.raises(ValueError):                   # backbone/__init__.py:13-14
+        OnePosePlus_model(cfg)
+    cfg = default_config()
+    cfg["keypoints_encoding"]["type"] = "mlp_conv"
+    with pytest.raises(NotImplementedError):          # OnePosePlusModel.py:47-50
+        OnePosePlus_model(cfg)
+    cfg = default_config()
+    cfg["coarse_matching"]["type"] = "sinkhorn"
+    with pytest.raises(NotImplementedError):          # coarse_matching.py:63-66
+        OnePosePlus_model(cfg)
+    cfg = default_config()
+    cfg["loftr_coarse"]["layer_names"] = ["self", "foo"]
+    with pytest.raises(NotImplementedError):          # transformer.py:117-120
+        OnePosePlus_model(cfg)
+
+
+def test_inference_only_and_no_cpu_fallback():
+    m = OnePosePlus_model(default_config())
+    with pytest.raises(RuntimeError, match="inference-only"):
+        m({"query_image": torch.zeros(1, 1, 64, 64)})
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m({"query_image": torch.zeros(1, 1, 64, 64)})
+    with pytest.raises(NotImplementedError):
+        m({"query_image": torch.zeros(1, 1, 64, 64), "query_image_mask": torch.ones(1, 8, 8)})
+
+
+def test_product_never_imports_oracle():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "onepose_plus_plus_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

@@ -73,8 +73,9 @@ def test_tokens_and_transformer(small):
 @pytest.mark.parametrize("name", list(MATCHER_CASES))
 def test_matcher_vs_golden(small, name):
     from tests import hip_ops as ops
-    _, _, _, model0, _ = small
+    from onepose_plus_plus_amd.synthetic import make_state_dict
     cfg, f3d, f2d, data = H.matcher_setup(name)
+    model0 = ops.make_model(cfg, make_state_dict(cfg, 0))      # thr / border_rm come from cfg
     got = ops.coarse_match(model0, f3d[0], f2d[0], tuple(data["q_hw_c"]), data["keypoints3d"][0], 8.0,
                            data["query_image_scale"][0])
     gold = H.load_golden(name)

@@ -76,7 +76,9 @@ def t_stages():
     stat("transformer f3", out[L:], torch.from_numpy(gold["f3"][0]))
     for name in ("matcher_n700_p300", "matcher_n5000_p3000"):
         c2, f3d, f2d, d = H.matcher_setup(name)
-        got = ops.coarse_match(model, f3d[0], f2d[0], tuple(d["q_hw_c"]), d["keypoints3d"][0], 8.0, d["query_image_scale"][0])
+        from onepose_plus_plus_amd.synthetic import make_state_dict
+        mm = ops.make_model(c2, make_state_dict(c2, 0))
+        got = ops.coarse_match(mm, f3d[0], f2d[0], tuple(d["q_hw_c"]), d["keypoints3d"][0], 8.0, d["query_image_scale"][0])
         g = H.load_golden(name)
         print("  %s: M got %d gold %d  ids equal %s" % (name, len(got["i_ids"]), len(g["i_ids"]),
               len(got["i_ids"]) == len(g["i_ids"]) and bool((got["i_ids"].numpy() == g["i_ids"]).all() and (got["j_ids"].numpy() == g["j_ids"]).all())))
