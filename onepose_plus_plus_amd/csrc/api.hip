@@ -517,7 +517,12 @@ size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, T
   b.kv = a.f((size_t)2 * n_seg * C * D);
   b.ks = a.f((size_t)2 * n_seg * C);
   const int ch = opp_linattn_chunks(len0) > opp_linattn_chunks(len1) ? opp_linattn_chunks(len0) : opp_linattn_chunks(len1);
-  b.scratch = a.f((size_t)n_seg * ch * (C * D + C));
+  size_t sc = (size_t)n_seg * ch * (C * D + C);
+  if (n_seg == 1 && C == 256) {
+    const size_t pair = opp_linattn_pair_scratch_floats(len0, len1);
+    sc = pair > sc ? pair : sc;
+  }
+  b.scratch = a.f(sc);
   return a.off;
 }
 
@@ -583,11 +588,16 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     }
     const float* q0 = b.qkv;
     const float* q1 = b.qkv + (size_t)T0 * 3 * C;
+    if (n_seg == 1 && C == 256 && D == 32) {   // coarse level: MFMA KV reduction, both streams per launch
+      OPP_TRY(opp_linattn_kv_pair(b.qkv, 3 * C, len0, len1, kv0, ks0, b.scratch, s));
+      OPP_TRY(opp_linattn_apply_pair(b.qkv, 3 * C, kv0, ks0, cross ? 1 : 0, b.msg, C, len0, len1, eps_attn, s));
+    } else {
     OPP_TRY(opp_linattn_kv(q0 + C, q0 + 2 * C, 3 * C, n_seg, len0, C, D, kv0, ks0, b.scratch, s));
     OPP_TRY(opp_linattn_kv(q1 + C, q1 + 2 * C, 3 * C, n_seg, len1, C, D, kv1, ks1, b.scratch, s));
     // self: each stream attends to itself; cross: to the other stream's (pre-update) K,V (quirk q6)
     OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, b.msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps_attn, s));
     OPP_TRY(opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, b.msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps_attn, s));
+    }
     OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s));          // merge (:86)
     OPP_TRY(opp_layernorm(b.mrg, C, e.g1, e.b1, nullptr, 0, b.msg, C, T, C, eps_ln, s));              // norm1 (:87)
     OPP_TRY(dense_gemm(X, C, b.msg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s));            // mlp.0 on cat([x,msg]) (:91)

@@ -199,6 +199,139 @@ __global__ __launch_bounds__(C) void linattn_apply_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Coarse level (one segment per stream, C = 256, D = 32): KV / Ksum on the fp32 MFMA.
+// One block = one chunk of 128 tokens of ONE stream, one wave per head:
+//   KV_h[d][v] += sum_t K[t][h*32+d] * V[t][h*32+v]   ==  mfma_32x32x2(A = K^T, B = V), 2 tokens / MFMA
+// Both streams are covered by one launch; partials [chunk][h][d][v] are summed in fixed order
+// by linattn_reduce_pair_kernel (deterministic).
+// ---------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(512) void linattn_kv_mfma_kernel(const float* __restrict__ qkv, int ld, int len0, int len1,
+                                                              int chunks0, float* __restrict__ kv_part,
+                                                              float* __restrict__ ks_part) {
+  constexpr int C = 256, CHUNK = 128;
+  const int chunk = blockIdx.x;
+  const int stream = chunk >= chunks0 ? 1 : 0;
+  const int cidx = stream ? chunk - chunks0 : chunk;
+  const int seg_len = stream ? len1 : len0;
+  const int tok0 = stream ? len0 : 0;
+  const int s_begin = cidx * CHUNK;
+  const int s_end = min(seg_len, s_begin + CHUNK);
+  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* kbase = qkv + (size_t)tok0 * ld + C + h * 32 + l31;
+  const float* vbase = kbase + C;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ksum = 0.f;
+  for (int s = s_begin; s < s_end; s += 16) {
+    float kk[8], vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = s + 2 * u + half;
+      const bool ok = t < s_end;
+      kk[u] = ok ? kbase[(size_t)t * ld] : 0.f;
+      vv[u] = ok ? vbase[(size_t)t * ld] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[u], vv[u], acc, 0, 0, 0);
+      ksum += kk[u];
+    }
+  }
+  float* kvp = kv_part + (size_t)chunk * (C * 32) + h * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+    kvp[d * 32 + l31] = acc[r];
+  }
+  const float tot = ksum + __shfl_xor(ksum, 32, 64);
+  if (half == 0) ks_part[(size_t)chunk * C + h * 32 + l31] = tot;
+}
+
+// out_kv [2][8192], out_ks [2][256] ; blockIdx.y = stream
+__global__ __launch_bounds__(256) void linattn_reduce_pair_kernel(const float* __restrict__ kv_part,
+                                                                 const float* __restrict__ ks_part, int chunks0,
+                                                                 int chunks1, float* __restrict__ out_kv,
+                                                                 float* __restrict__ out_ks) {
+  constexpr int KV = 8192, C = 256;
+  const int stream = blockIdx.y;
+  const int c_begin = stream ? chunks0 : 0;
+  const int c_end = stream ? chunks0 + chunks1 : chunks0;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < KV) {
+    float s = 0.f;
+    for (int c = c_begin; c < c_end; ++c) s += kv_part[(size_t)c * KV + i];
+    out_kv[stream * KV + i] = s;
+  } else if (i < KV + C) {
+    const int j = i - KV;
+    float s = 0.f;
+    for (int c = c_begin; c < c_end; ++c) s += ks_part[(size_t)c * C + j];
+    out_ks[stream * C + j] = s;
+  }
+}
+
+// apply for both streams in one launch (C = 256, D = 32, one segment per stream)
+__global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __restrict__ qkv, int ld,
+                                                                const float* __restrict__ kv,
+                                                                const float* __restrict__ ks, int cross,
+                                                                float* __restrict__ out, int ldo, int len0, int len1,
+                                                                int chunks0, float eps) {
+  constexpr int C = 256, D = 32, TB = 8, CHUNK = 32;
+  __shared__ __attribute__((aligned(16))) float qsh[TB][C];
+  const int t = threadIdx.x;
+  const int h = t / D, v = t % D;
+  const int stream = blockIdx.x >= chunks0 ? 1 : 0;
+  const int cidx = stream ? blockIdx.x - chunks0 : blockIdx.x;
+  const int seg_len = stream ? len1 : len0;
+  const int base = stream ? len0 : 0;
+  const int src = cross ? 1 - stream : stream;          // quirk q6: both streams use pre-update K,V
+  const float src_len = (float)(src ? len1 : len0);
+  const int s_begin = cidx * CHUNK;
+  const int s_end = min(seg_len, s_begin + CHUNK);
+  float kvr[D], ksr[D];
+  const float* kvp = kv + (size_t)src * (C * D);
+  const float* ksp = ks + (size_t)src * C;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    kvr[d] = kvp[(h * D + d) * D + v];
+    ksr[d] = ksp[h * D + d];
+  }
+  for (int s0 = s_begin; s0 < s_end; s0 += TB) {
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int s = s0 + j;
+      qsh[j][t] = s < s_end ? qkv[(size_t)(base + s) * ld + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+      const int s = s0 + j;
+      if (s >= s_end) break;
+      const float4* qr = reinterpret_cast<const float4*>(&qsh[j][h * D]);
+      float num = 0.f, den = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 q4 = qr[d4];
+        num = fmaf(q4.x, kvr[d4 * 4 + 0], num);
+        den = fmaf(q4.x, ksr[d4 * 4 + 0], den);
+        num = fmaf(q4.y, kvr[d4 * 4 + 1], num);
+        den = fmaf(q4.y, ksr[d4 * 4 + 1], den);
+        num = fmaf(q4.z, kvr[d4 * 4 + 2], num);
+        den = fmaf(q4.z, ksr[d4 * 4 + 2], den);
+        num = fmaf(q4.w, kvr[d4 * 4 + 3], num);
+        den = fmaf(q4.w, ksr[d4 * 4 + 3], den);
+      }
+      const float z = 1.0f / (den + eps);
+      out[(size_t)(base + s) * ldo + t] = (num * z) * src_len;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res,
@@ -265,5 +398,33 @@ int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks,
     return OPP_ERR_UNSUPPORTED;
   }
   OPP_CHECK_LAUNCH("linattn_apply_kernel");
+  return OPP_OK;
+}
+
+
+// ---- coarse level: both streams in three launches ------------------------------------------
+size_t opp_linattn_pair_scratch_floats(int len0, int len1) {
+  const size_t chunks = (size_t)opp_cdiv(len0, 128) + opp_cdiv(len1, 128);
+  return chunks * (8192 + 256);
+}
+
+// qkv [len0+len1][ld] with Q | K | V column blocks of 256.  kv [2][8192], ks [2][256].
+int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
+                        hipStream_t stream) {
+  const int c0 = opp_cdiv(len0, 128), c1 = opp_cdiv(len1, 128);
+  float* kvp = scratch;
+  float* ksp = scratch + (size_t)(c0 + c1) * 8192;
+  hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1), dim3(512), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
+  hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 256), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
+  OPP_CHECK_LAUNCH("linattn_kv_pair");
+  return OPP_OK;
+}
+
+int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
+                           int len0, int len1, float eps, hipStream_t stream) {
+  const int c0 = opp_cdiv(len0, 32), c1 = opp_cdiv(len1, 32);
+  hipLaunchKernelGGL(linattn_apply_pair_kernel, dim3(c0 + c1), dim3(256), 0, stream, qkv, ld, kv, ks, cross, out, ldo, len0, len1,
+                     c0, eps);
+  OPP_CHECK_LAUNCH("linattn_apply_pair_kernel");
   return OPP_OK;
 }

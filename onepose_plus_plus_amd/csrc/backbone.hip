@@ -24,7 +24,9 @@ __global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __r
   }
 }
 
-// w [Cout][Cin][kh][kw] (PyTorch) -> packed [Cout_pad][(ky*kw+kx)*Cin_pad + ci], optionally * scale[co]
+// w [Cout][Cin][kh][kw] (PyTorch) -> packed [Cout_pad][K], K ordered (32-channel group, tap, channel
+// in group): k = ((ci/32) * taps + tap) * 32 + ci % 32 -- the order the implicit-GEMM loader walks;
+// optionally * scale[co]
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ scale, int cout,
                                  int cin, int ks, int cout_pad, int cin_pad, float* __restrict__ out) {
   const int kpad = ks * ks * cin_pad;
@@ -32,8 +34,11 @@ __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __res
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int co = (int)(i / kpad);
     const int r = (int)(i - (size_t)co * kpad);
-    const int tap = r / cin_pad;
-    const int ci = r - tap * cin_pad;
+    const int taps = ks * ks;
+    const int grp = r / (taps * 32);
+    const int rem = r - grp * taps * 32;
+    const int tap = rem >> 5;
+    const int ci = grp * 32 + (rem & 31);
     float v = 0.f;
     if (co < cout && ci < cin) {
       v = w[((size_t)co * cin + ci) * ks * ks + tap];

@@ -22,6 +22,10 @@
 //  * Epilogue fused: folded-BN bias, residual (direct or bilinear x2 align_corners=True
 //    upsample of a half-resolution NHWC tensor), ReLU / LeakyReLU / elu+1 feature map, value
 //    scaling for the linear attention, temperature scaling for the score matrix.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include <vector>
 
 #include "opp_common.h"
@@ -32,14 +36,16 @@ namespace {
 
 constexpr int kLdsStride = 36;  // floats per LDS tile row: 32 + 4 pad (keeps 16 B alignment)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int TM = BM / WAVES_M / 32;
-  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int NT32 = BN / 32;                               // 32-column sub-tiles per block
+  constexpr int TN = (NT32 + WAVES_N - 1) / WAVES_N;          // per wave (last wave may own fewer)
+  constexpr bool kRagged = (NT32 % WAVES_N) != 0;             // e.g. 224 columns on 2 waves = 4 + 3
   constexpr int A_LD = BM * 8 / NT;
   constexpr int B_LD = BN * 8 / NT;
-  static_assert(BM % (WAVES_M * 32) == 0 && BN % (WAVES_N * 32) == 0, "tile shape");
+  static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "load split");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -49,93 +55,161 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave / WAVES_N;
-  const int wn = wave % WAVES_N;
+  const int wm = __builtin_amdgcn_readfirstlane(wave / WAVES_N);
+  const int wn = __builtin_amdgcn_readfirstlane(wave % WAVES_N);
+  bool tile_ok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) tile_ok[j] = kRagged ? (wn * TN + j < NT32) : true;
   const int half = lane >> 5;
   const int l31 = lane & 31;
 
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only,
+  // never correctness), so hand each XCD a CONTIGUOUS range of tiles: vertically adjacent image
+  // tiles (3x3 halo rows) and tiles sharing an A panel then hit the same 4 MiB L2.
   const int tiles_n = (g.n_store + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n;
-  const int tile_n = blockIdx.x - tile_m * tiles_n;
+  int tile_lin = blockIdx.x;
+  if (g.xcd_swizzle) {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tile_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = tile_lin / tiles_n;
+  const int tile_n = tile_lin - tile_m * tiles_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
 
   const int kq = tid & 7;     // which float4 of the 32-float chunk this thread moves
   const int lrow = tid >> 3;  // tile row of the first load slot; slot i adds i*(NT/8)
 
-  // ---- per-thread A row descriptors -------------------------------------------------
-  int a_iy0[A_LD], a_ix0[A_LD], a_pix[A_LD];   // conv mode
-  int a_off0[A_LD], a_off1[A_LD];              // dense mode
-  bool a_ok[A_LD];
+  // ---- operand loaders: raw buffer loads, branch-free ------------------------------------
+  // Out-of-range lanes (padding halo of the convolution, rows >= M, weight rows >= N) get a
+  // byte offset beyond num_records: the buffer unit returns zeros, so there is no exec-masked
+  // control flow in the K loop and the loads can be scheduled among the MFMAs.
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, g.a0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A1 ? g.A1 : g.A0), 0, g.A1 ? g.a1_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, g.w_bytes, 0x00020000);
+
+  // byte offset of each load slot's row start (+ this thread's float4); kOob for rows >= M.
+  // conv mode: a_mask bit t = tap t of the window falls inside the image for this output pixel.
+  unsigned a_base0[A_LD], a_base1[A_LD], a_mask[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
     const int r = m0 + lrow + i * (NT / 8);
-    a_ok[i] = r < g.M;
     if (CONV) {
       const int ox = r % g.Wout;
       const int t = r / g.Wout;
       const int oy = t % g.Hout;
       const int b = t / g.Hout;
-      a_iy0[i] = a_ok[i] ? oy * g.stride - g.pad : -(1 << 28);
-      a_ix0[i] = ox * g.stride - g.pad;
-      a_pix[i] = b * g.Hin * g.Win;
-      a_off0[i] = a_off1[i] = 0;
+      const int iy0 = oy * g.stride - g.pad;
+      const int ix0 = ox * g.stride - g.pad;
+      a_base0[i] = (unsigned)(((b * g.Hin + iy0) * g.Win + ix0) * g.Cin + kq * 4) * 4u;
+      a_base1[i] = 0;
+      unsigned m = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const bool ok = ky < g.ksize && kx < g.ksize && (unsigned)(iy0 + ky) < (unsigned)g.Hin &&
+                          (unsigned)(ix0 + kx) < (unsigned)g.Win;
+          m |= (ok ? 1u : 0u) << (ky * g.ksize + kx);
+        }
+      a_mask[i] = r < g.M ? m : 0u;
     } else {
-      a_off0[i] = r * g.lda0;
-      a_off1[i] = r * g.lda1;
-      a_iy0[i] = a_ix0[i] = a_pix[i] = 0;
+      a_base0[i] = r < g.M ? (unsigned)(r * g.lda0 + kq * 4) * 4u : kOob;
+      a_base1[i] = r < g.M ? (unsigned)(r * g.lda1 + kq * 4) * 4u : kOob;
+      a_mask[i] = 0;
     }
   }
-  int b_off[B_LD];
-  bool b_ok[B_LD];
+  unsigned b_base[B_LD];
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
     const int n = n0 + lrow + i * (NT / 8);
-    b_ok[i] = n < g.N;
-    b_off[i] = n * g.ldw;
+    b_base[i] = n < g.N ? (unsigned)(n * g.ldw + kq * 4) * 4u : kOob;
   }
 
-  float4 a_reg[A_LD], b_reg[B_LD];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto bload = [](const __amdgpu_buffer_rsrc_t r, unsigned off) -> float4 {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  };
 
-  auto load_global = [&](int kc) {
-    const int k0 = kc * 32;
+  // wave-uniform K-chunk cursor of the global prefetch (no per-chunk integer division).
+  //
+  // The K chunks are visited in a ROTATED order that differs from workgroup to workgroup:
+  // every workgroup walks the chunks in lockstep, and chunk k of every row lives at the same
+  // offset inside the (512 B .. 3 KB) row record, i.e. on the same few L2 channels.  With all
+  // 512 workgroups on the same chunk the activation loads were served by a quarter of the
+  // channels (measured: ~3.3 TB/s cap, 15-25 % of the kernel in vmcnt waits).  Starting
+  // workgroup t at chunk (t mod n) spreads the accesses over all channels; the sum over k is
+  // order-independent, and the order is a fixed function of the tile index (deterministic).
+  const int nk = g.K / 32;
+  const int taps = CONV ? g.ksize * g.ksize : 1;
+  const int ngrp = CONV ? g.Cin / 32 : nk;            // rotation period: channel groups / chunks
+  int cur_i = 0;                                      // chunks issued so far
+  int cur_grp = (tile_m + tile_n) % ngrp;             // channel group (conv) or chunk index (dense)
+  int cur_tap = 0, cur_ky = 0, cur_kx = 0;
+  int cur_k0 = CONV ? cur_grp * taps * 32 : cur_grp * 32;
+  unsigned cur_delta = CONV ? (unsigned)(cur_grp * 32) * 4u : 0u;
+  unsigned cur_past = 0;
+  auto advance = [&]() {
+    ++cur_i;
+    cur_past = cur_i < nk ? 0u : kOob;
     if (CONV) {
-      const int tap = k0 / g.Cin;
-      const int c0 = k0 - tap * g.Cin;
-      const int ky = tap / g.ksize;
-      const int kx = tap - ky * g.ksize;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        const int iy = a_iy0[i] + ky;
-        const int ix = a_ix0[i] + kx;
-        const bool inb = (unsigned)iy < (unsigned)g.Hin && (unsigned)ix < (unsigned)g.Win;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (inb) {
-          const size_t off = (size_t)(a_pix[i] + iy * g.Win + ix) * g.Cin + c0 + kq * 4;
-          v = *reinterpret_cast<const float4*>(g.A0 + off);
-        }
-        a_reg[i] = v;
+      ++cur_tap;
+      if (++cur_kx == g.ksize) {
+        cur_kx = 0;
+        ++cur_ky;
       }
+      if (cur_tap == taps) {
+        cur_tap = 0;
+        cur_ky = 0;
+        cur_kx = 0;
+        if (++cur_grp == ngrp) cur_grp = 0;
+      }
+      cur_k0 = (cur_grp * taps + cur_tap) * 32;
+      cur_delta = (unsigned)((cur_ky * g.Win + cur_kx) * g.Cin + cur_grp * 32) * 4u;
     } else {
-      const bool first = k0 < g.ksplit;
-      const float* base = first ? g.A0 : g.A1;
-      const int kk = (first ? k0 : k0 - g.ksplit) + kq * 4;
-#pragma unroll
-      for (int i = 0; i < A_LD; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a_ok[i]) v = *reinterpret_cast<const float4*>(base + (first ? a_off0[i] : a_off1[i]) + kk);
-        a_reg[i] = v;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_ok[i]) v = *reinterpret_cast<const float4*>(g.W + b_off[i] + k0 + kq * 4);
-      b_reg[i] = v;
+      if (++cur_grp == ngrp) cur_grp = 0;
+      cur_k0 = cur_grp * 32;
     }
   };
 
-  auto store_lds = [&](int buf) {
+  // global -> registers for the chunk the cursor points at; item i in [0, A_LD + B_LD) is one
+  // buffer_load_dwordx4 so that the loads can be issued one at a time between MFMAs.
+  // Chunks past the end of K (the pipeline always runs an even number of chunks and prefetches
+  // two ahead) read out of range -> zeros: they contribute exactly 0 to the accumulators.
+  auto load_item = [&](int i, float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
+    if (ABL == 6 && i >= A_LD) return;   // ablation: no weight loads
+    if (ABL == 7 && i < A_LD) return;    // ablation: no activation loads
+    const unsigned past = cur_past;
+    if (i < A_LD) {
+      if (CONV) {
+        // pure data flow (no exec masking): invalid tap -> bit 31 set -> out of range -> zeros
+        const unsigned bad = (((a_mask[i] >> cur_tap) & 1u) - 1u) & kOob;
+        a_reg[i] = bload(rsrc_a0, (a_base0[i] + cur_delta) | past | bad);
+      } else if (cur_k0 < g.ksplit) {
+        // (kOob + small) stays out of range, so invalid rows need no select
+        a_reg[i] = bload(rsrc_a0, (a_base0[i] + (unsigned)cur_k0 * 4u) | past);
+      } else {
+        a_reg[i] = bload(rsrc_a1, (a_base1[i] + (unsigned)(cur_k0 - g.ksplit) * 4u) | past);
+      }
+    } else {
+      b_reg[i - A_LD] = bload(rsrc_w, (b_base[i - A_LD] + (unsigned)cur_k0 * 4u) | past);
+    }
+  };
+  auto load_global = [&](float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
+#pragma unroll
+    for (int i = 0; i < A_LD + B_LD; ++i) load_item(i, a_reg, b_reg);
+  };
+
+  auto store_item = [&](int i, int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
+    if (i < A_LD)
+      *reinterpret_cast<float4*>(As + buf * BM * kLdsStride + (lrow + i * (NT / 8)) * kLdsStride + kq * 4) = a_reg[i];
+    else
+      *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + (lrow + (i - A_LD) * (NT / 8)) * kLdsStride + kq * 4) = b_reg[i - A_LD];
+  };
+  auto store_lds = [&](int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
     float* as = As + buf * BM * kLdsStride;
     float* bs = Bs + buf * BN * kLdsStride;
 #pragma unroll
@@ -154,51 +228,132 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / 32;
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
   const int a_frag = (wm * TM * 32 + l31) * kLdsStride + half * 16;
   const int b_frag = (wn * TN * 32 + l31) * kLdsStride + half * 16;
 
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nk) load_global(kc + 1);
-    const float* as = As + cur * BM * kLdsStride + a_frag;
-    const float* bs = Bs + cur * BN * kLdsStride + b_frag;
+  // LDS -> MFMA operand fragments of ONE k-quarter (8 k values: 4 per lane half) of a chunk
+  auto read_frags = [&](int buf, int q, float4 (&af)[TM], float4 (&bf)[TN]) {
+    const float* as = As + buf * BM * kLdsStride + a_frag + q * 4;
+    const float* bs = Bs + buf * BN * kLdsStride + b_frag + q * 4;
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      float4 af[TM], bf[TN];
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLdsStride);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLdsStride + k4 * 4);
+    for (int j = 0; j < TN; ++j)
+      if (tile_ok[j]) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * kLdsStride);
+  };
+  // TM*TN*4 MFMAs on one k-quarter.  `between(n)` runs after the n-th MFMA was issued: the
+  // pipeline uses it to issue ONE buffer load or ONE LDS write in the 64-cycle shadow of each
+  // v_mfma_f32_32x32x2_f32 (a VMEM instruction costs ~60 issue cycles, measured as 15 % of the
+  // kernel when all eight were issued back to back at the top of the chunk).
+  auto mfma_quarter = [&](const float4 (&af)[TM], const float4 (&bf)[TN], auto&& between) {
+    int n = 0;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * kLdsStride + k4 * 4);
+    for (int e = 0; e < 4; ++e) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if (tile_ok[j]) {
+            const float av = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+            const float bv = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+          between(n);
+          ++n;
+        }
+      }
     }
-    if (kc + 1 < nk) store_lds(cur ^ 1);
-    __syncthreads();
+  };
+  auto nothing = [](int) {};
+  constexpr int kSlots = TM * TN * 4;                     // MFMA issue slots per quarter
+  constexpr int kItems = A_LD + B_LD;                     // loads (and LDS writes) per chunk
+  constexpr int kStride = kSlots / kItems > 0 ? kSlots / kItems : 1;
+
+  // ---- software-pipelined K loop ----------------------------------------------------------
+  // Per chunk c (LDS buffer c&1; 4 k-quarters q0..q3 of TM*TN*4 MFMAs each; two operand
+  // fragment register sets f0/f1 alternate per quarter):
+  //   issue global loads of chunk c+2 (register set c&1)     -- two chunks of latency budget
+  //   read q1 | MFMA q0
+  //   read q2 | MFMA q1
+  //   LDS-write chunk c+1 (register set (c+1)&1, loaded during chunk c-1) into buffer (c+1)&1
+  //   read q3 | MFMA q2
+  //   barrier   (every read of buffer c&1 and every write of buffer (c+1)&1 is complete)
+  //   read q0 of chunk c+1 | MFMA q3                          -- covers barrier skew + LDS latency
+  // so the matrix pipe never waits for a global load, an LDS write or the barrier.
+  float4 ga[DEPTH][A_LD], gb[DEPTH][B_LD];   // DEPTH chunks of global prefetch in registers
+  float4 fa[2][TM], fb[2][TN];
+  float4 da[A_LD], db[B_LD];   // ablation 5 only: load sink that is never consumed in the loop
+
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    if (d) advance();
+    load_global(ga[d], gb[d]);
+  }
+  store_lds(0, ga[0], gb[0]);
+  __syncthreads();
+  read_frags(0, 0, fa[0], fb[0]);
+
+  // The chunk body has no branches: the waitcnt pass can prove that the chunk c+1 registers are
+  // the OLDEST loads in flight and waits with a counted vmcnt instead of draining the freshly
+  // issued prefetch.  The prefetch / LDS hand-over past the last chunk is harmless
+  // (out-of-range loads return zeros, the extra LDS buffer is never consumed).
+  // `set` = c % DEPTH is compile-time (register arrays), the LDS buffer c & 1 is run-time.
+  auto chunk = [&](auto set, int lb) {
+    constexpr int P = decltype(set)::value;
+    constexpr int PN = (P + 1) % DEPTH;              // register set holding chunk c+1
+    constexpr int A2 = ABL == 5 ? 1 : (ABL >= 6 ? 0 : ABL);   // ablation 5 behaves like 1 apart from the sink loads
+    const int B0 = A2 >= 2 ? 0 : lb;
+    const int B1 = A2 >= 2 ? 0 : lb ^ 1;
+    if (ABL < 1 || ABL >= 5) advance();
+    if (A2 < 3) read_frags(B0, 1, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quarter(fa[0], fb[0], [&](int n) {          // q0 + prefetch of chunk c+DEPTH, one load per slot
+      if ((ABL < 1 || ABL >= 5) && n % kStride == 0 && n / kStride < kItems) {
+        if (ABL == 5) load_item(n / kStride, da, db);
+        else load_item(n / kStride, ga[P], gb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    if (ABL < 1 || ABL >= 6) {                        // loads that did not fit into the slots
+#pragma unroll
+      for (int i = kSlots / kStride; i < kItems; ++i) load_item(i, ga[P], gb[P]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (A2 < 3) read_frags(B0, 2, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quarter(fa[1], fb[1], nothing);
+    __builtin_amdgcn_sched_barrier(0);
+    if (A2 < 3) read_frags(B0, 3, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quarter(fa[0], fb[0], [&](int n) {          // q2 + LDS hand-over of chunk c+1
+      if (A2 < 2 && n % kStride == 0 && n / kStride < kItems) {
+        store_item(n / kStride, B1, ga[PN], gb[PN]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+    if (A2 < 2) {
+#pragma unroll
+      for (int i = kSlots / kStride; i < kItems; ++i) store_item(i, B1, ga[PN], gb[PN]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (A2 < 2) __syncthreads();
+    if (A2 < 3) read_frags(B1, 0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_quarter(fa[1], fb[1], nothing);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
+  for (int c = 0; c < nk; c += DEPTH) {
+    chunk(std::integral_constant<int, 0>{}, c & 1);
+    if (DEPTH > 1) chunk(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+    if (DEPTH > 2) chunk(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
+    if (DEPTH > 3) chunk(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
+  }
+  if (ABL == 5) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) asm volatile("" ::"v"(da[i].x), "v"(da[i].w));
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) asm volatile("" ::"v"(db[i].x), "v"(db[i].w));
   }
 
   // ---- epilogue -----------------------------------------------------------------------
@@ -237,7 +392,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 32 + j * 32 + l31;
-        if (col >= g.n_store) continue;
+        if (!tile_ok[j] || col >= g.n_store) continue;
         float v = acc[i][j][r];
         if (scale_on) v = (v * g.out_mul) / g.out_div;
         if (g.bias) v += g.bias[col];
@@ -275,13 +430,24 @@ struct GemmProfiler {
   long long dropped = 0;
 } g_prof;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int ABL>
+int launch_ablate(const OppGemm& g, hipStream_t stream) {   // tuning only: 128x128 conv with parts removed
+  const size_t lds = (size_t)2 * (128 + 128) * kLdsStride * sizeof(float);
+  auto k = opp_gemm_kernel<128, 128, 2, 2, true, ABL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128)), dim3(256), lds, stream, g);
+  OPP_CHECK_LAUNCH("opp_gemm_kernel(ablate)");
+  return OPP_OK;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH = 2>
 int launch_cfg(const OppGemm& g, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float);
+  static const size_t extra_lds = getenv("OPP_EXTRA_LDS") ? (size_t)atoi(getenv("OPP_EXTRA_LDS")) : 0;  // tuning knob
+  const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float) + extra_lds;
   const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
   if (g.conv) {
-    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true>;
+    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH>;
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -290,7 +456,7 @@ int launch_cfg(const OppGemm& g, hipStream_t stream) {
     }
     hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
   } else {
-    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false>;
+    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH>;
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -305,26 +471,41 @@ int launch_cfg(const OppGemm& g, hipStream_t stream) {
 
 }  // namespace
 
-int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
+int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
+  OppGemm g = g_in;
+  static const int xcd_env = getenv("OPP_XCD_SWIZZLE") ? atoi(getenv("OPP_XCD_SWIZZLE")) : 1;
+  g.xcd_swizzle = xcd_env;
   OPP_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm: bad M/N/K (%d,%d,%d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.n_store >= g.N && g.C && g.W && g.A0, "gemm: bad output/operands");
   OPP_CHECK_ARG((size_t)g.M * (size_t)g.ldc < (1ull << 31), "gemm: output too large for 32-bit indexing");
+  g.w_bytes = (unsigned)((size_t)g.N * g.ldw * 4);
+  OPP_CHECK_ARG((size_t)g.N * g.ldw * 4 < (1ull << 31), "gemm: weight operand too large for buffer addressing");
   if (g.conv) {
     OPP_CHECK_ARG(g.Cin % 32 == 0 && g.K == g.ksize * g.ksize * g.Cin, "conv: Cin %% 32 / K mismatch");
     OPP_CHECK_ARG(g.M == g.Bn * g.Hout * g.Wout, "conv: M != B*Hout*Wout");
+    const size_t ab = (size_t)g.Bn * g.Hin * g.Win * g.Cin * 4;
+    OPP_CHECK_ARG(ab < (1ull << 31), "conv: input too large for buffer addressing");
+    g.a0_bytes = (unsigned)ab;
   } else {
+    const size_t a0b = ((size_t)(g.M - 1) * g.lda0 + (g.ksplit < g.K ? g.ksplit : g.K)) * 4;
+    const size_t a1b = g.A1 ? ((size_t)(g.M - 1) * g.lda1 + (g.K - g.ksplit)) * 4 : 0;
+    OPP_CHECK_ARG(a0b < (1ull << 31) && a1b < (1ull << 31), "gemm: A operand too large for buffer addressing");
+    g.a0_bytes = (unsigned)a0b;
+    g.a1_bytes = (unsigned)a1b;
     OPP_CHECK_ARG(g.ksplit % 32 == 0 && (g.ksplit >= g.K || g.A1), "gemm: bad ksplit");
     OPP_CHECK_ARG(g.res_mode != OPP_RES_BILINEAR2X, "gemm: bilinear residual needs conv mode");
   }
   if (cfg < 0) {
-    const int cus = 256;
+    // Tile choice from the MI355X micro-bench (tools/conv_bench.py): 256 CUs, 4 SIMDs each.
     if (g.n_store % 224 == 0) {
-      cfg = (opp_cdiv(g.M, 128) * (g.n_store / 224) >= cus) ? 3 : 4;
+      // 196(->224)-channel stages: 128x224 (4 waves x 32x224) when M fills >= 2 rounds of CUs,
+      // else 64x224 with the columns split 128 + 96 over two wave columns (all 4 SIMDs busy)
+      cfg = (opp_cdiv(g.M, 128) * (g.n_store / 224) >= 384) ? 3 : 5;
     } else {
       const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
       const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
-      if (t0 >= cus + cus / 2) cfg = 0;
-      else if (t1 >= cus) cfg = 1;
+      if (t0 >= 384) cfg = 0;
+      else if (t1 >= 512) cfg = 1;
       else cfg = 2;
     }
   }
@@ -345,6 +526,17 @@ int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
     case 2: rc = launch_cfg<64, 64, 2, 2>(g, stream); break;
     case 3: rc = launch_cfg<128, 224, 4, 1>(g, stream); break;
     case 4: rc = launch_cfg<64, 224, 2, 1>(g, stream); break;
+    case 5: rc = launch_cfg<64, 224, 2, 2>(g, stream); break;   // 4 waves: N split 128 + 96
+    case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // prefetch depth experiments
+    case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
+    case 13: rc = launch_cfg<128, 224, 4, 1, 3>(g, stream); break;
+    case 15: rc = launch_cfg<64, 224, 2, 2, 3>(g, stream); break;
+    case 101: rc = g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID; break;
+    case 102: rc = g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID; break;
+    case 103: rc = g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID; break;
+    case 105: rc = g.conv ? launch_ablate<5>(g, stream) : OPP_ERR_INVALID; break;
+    case 106: rc = g.conv ? launch_ablate<6>(g, stream) : OPP_ERR_INVALID; break;
+    case 107: rc = g.conv ? launch_ablate<7>(g, stream) : OPP_ERR_INVALID; break;
     default: opp_set_error("gemm: unknown tile config %d", cfg); return OPP_ERR_INVALID;
   }
   if (rec) {

@@ -79,6 +79,9 @@ struct OppGemm {
   float s0 = 1.f, s1 = 1.f;
   // generic output scaling: y = acc * out_mul / out_div (applied first; used by the score GEMM)
   float out_mul = 1.f, out_div = 1.f;
+  // operand extents in bytes for the buffer descriptors (filled by the launcher)
+  unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;
+  int xcd_swizzle = 1;
   // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
   double alg_flops = 0.0;
 };

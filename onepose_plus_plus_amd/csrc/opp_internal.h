@@ -10,6 +10,11 @@ int opp_linattn_kv(const float* k, const float* v, int ld, int n_seg, int seg_le
                    float* ks_out, float* scratch, hipStream_t stream);
 int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks, float* out, int ldo, int n_seg,
                       int seg_len, int src_len, int C, int D, float eps, hipStream_t stream);
+size_t opp_linattn_pair_scratch_floats(int len0, int len1);
+int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
+                        hipStream_t stream);
+int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
+                           int len0, int len1, float eps, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);

@@ -1,0 +1,103 @@
+"""Micro-bench of the implicit-GEMM conv / dense GEMM kernel on the backbone / transformer
+layer shapes (HIP-event timing through torch on the launch stream).
+
+    python tools/conv_bench.py [--only NAME] [--iters 20]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from onepose_plus_plus_amd import _lib  # noqa: E402
+
+# name, Hin, Win, cin, cout, ks, stride, cfgs
+CONVS = [
+    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 106, 107, 101, 105, 102, 103]),
+    ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11]),
+    ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 13]),
+    ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 15]),
+    ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [4, 5]),
+    ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1, [1, 0, 2]),
+    ("layer3 3x3 256->256 @64", 64, 64, 256, 256, 3, 1, [2, 1]),
+]
+# name, M, K, N, cfgs
+DENSE = [
+    ("dense 65536x1152x128", 65536, 1152, 128, [0]),
+    ("dense 65536x128x128", 65536, 128, 128, [0]),
+    ("qkv 9096x256x768", 9096, 256, 768, [0, 1]),
+    ("merge 9096x256x256", 9096, 256, 256, [1, 2, 0]),
+    ("mlp1 9096x512x512", 9096, 512, 512, [0, 1]),
+    ("mlp2 9096x512x256", 9096, 512, 256, [1, 2, 0]),
+    ("score 5000x256x4096", 5000, 256, 4096, [0]),
+]
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    for name, H, W, cin, cout, ks, stride, cfgs in CONVS:
+        if args.only and args.only not in name:
+            continue
+        cip, cop = pad32(cin), pad32(cout)
+        x = torch.randn(H, W, cip, device="cuda")
+        w = torch.randn(cop, ks * ks * cip, device="cuda") * 0.02
+        Ho, Wo = H // stride, W // stride
+        y = torch.empty(Ho, Wo, cop, device="cuda")
+        bias = torch.randn(cop, device="cuda")
+        alg = 2.0 * Ho * Wo * cout * ks * ks * cin
+        padf = 2.0 * Ho * Wo * cop * ks * ks * cip
+        for cfg in cfgs:
+            if cfg in (3, 4, 5, 13, 15) and cop % 224:
+                continue
+            if cfg >= 100 and not os.environ.get("OPP_ABLATE"):
+                continue
+            if cfg in (0, 1, 2, 10, 11) and cop % 224 == 0:
+                continue
+
+            def fn():
+                _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cip, w.data_ptr(), bias.data_ptr(), cop, ks, stride,
+                                               None, 0, 1, y.data_ptr(), cfg, s), "conv")
+            try:
+                us = timeit(fn, args.iters)
+                print("%-32s cfg%d  %8.1f us  alg %6.1f TF  padded %6.1f TF" % (name, cfg, us, alg / us / 1e6, padf / us / 1e6), flush=True)
+            except Exception as e:
+                print("%-32s cfg%d  FAILED %s" % (name, cfg, e), flush=True)
+    for name, M, K, N, cfgs in DENSE:
+        if args.only and args.only not in name:
+            continue
+        A = torch.randn(M, K, device="cuda")
+        Wt = torch.randn(N, K, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        for cfg in cfgs:
+            def fn():
+                _lib.check(lib.opp_linear(A.data_ptr(), M, K, Wt.data_ptr(), N, 0, C.data_ptr(), cfg, s), "linear")
+            us = timeit(fn, args.iters)
+            print("%-32s cfg%d  %8.1f us  %6.1f TF" % (name, cfg, us, 2.0 * M * K * N / us / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
