@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--thr", type=float, default=0.1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "2")),
+                    help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
+                         "2 Ray workers per GPU, inference_OnePosePlus.py:18-26); steps are split evenly")
     args = ap.parse_args()
 
     from onepose_plus_plus_amd import OnePosePlus_model, default_config, _lib
@@ -77,6 +80,15 @@ def main():
         broadcast_weights(model, sd, src=0)
     else:
         model.load_state_dict(sd, strict=True)
+    n_streams = max(1, args.streams)
+    if args.steps % n_streams:
+        raise SystemExit("--steps must be a multiple of --streams")
+    models = [model]
+    for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
+        m = OnePosePlus_model(cfg).eval().to(dev)
+        m.load_state_dict(model.state_dict(), strict=True)
+        models.append(m)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
 
     # one synthetic object per rank (seed = rank), a small pool of query images resident in HBM
     n_img = 4
@@ -91,11 +103,38 @@ def main():
     for d in datas:
         d.update(bank)          # the bank is per-object constant: one resident copy
 
-    def step(i):
+    def step(i, slot=0):
         d = dict(datas[i % n_img])
         with torch.no_grad():
-            model(d)
+            if streams[slot] is None:
+                models[slot](d)
+            else:
+                with torch.cuda.stream(streams[slot]):
+                    models[slot](d)
         return d
+
+    def run_steps(n):
+        """n forwards; with several streams one host thread per stream keeps its forward in flight
+        (the forward's single D2H sync of the match count releases the GIL)."""
+        if n_streams == 1:
+            last = None
+            for i in range(n):
+                last = step(i)
+            return last
+        import threading
+        out = [None] * n_streams
+
+        def worker(slot):
+            torch.cuda.set_device(dev)
+            for i in range(n // n_streams):
+                out[slot] = step(i * n_streams + slot, slot)
+            streams[slot].synchronize()
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return out[0]
 
     def barrier():
         if dist is not None:
@@ -103,15 +142,15 @@ def main():
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
-        step(i)
+        for k in range(n_streams):
+            step(i, k)
     lib = _lib.load()
     prof = (not args.no_roofline) and rank == 0 and world == 1
     barrier()
     if prof:
         _lib.check(lib.opp_profile_start(DOMINANT_CFG, DOMINANT_CONV, args.steps * 8), "profile_start")
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        last = step(i)
+    last = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     roof = None
@@ -142,9 +181,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded random image, descriptor bank and weights)",
-            "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1, "
-                                   "one object per GPU" % (args.hw, args.hw, args.n_points,
-                                                           " + fine refine" if args.fine else ""),
+            "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
+                                   "%d forward(s) in flight per GPU, one object per GPU"
+                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams),
+                       "streams_per_gpu": n_streams,
                        "matches_last_step": int(last["mconf"].numel()),
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),

@@ -357,17 +357,68 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   }
 
   // ---- epilogue -----------------------------------------------------------------------
+  // The MFMA accumulator layout puts 32 consecutive COLUMNS of one row on 32 lanes (4 B per
+  // lane per store).  Stage the tile through the (now idle) LDS operand buffers and write it
+  // out row-contiguously with 16 B per lane: full 128 B lines for the stores, the residual and
+  // the bias, and the per-row work (bilinear taps, value scaling) is done once per 4 outputs.
+  constexpr int JP = TN < 4 ? TN : 4;                      // n-subtiles per wave staged per pass
+  constexpr int NPASS = (TN + JP - 1) / JP;
+  constexpr int WP = WAVES_N * JP * 32;                    // staged columns per pass
+  constexpr int CS = WP + 4;                               // LDS row stride (floats)
+  static_assert((size_t)BM * CS * 4 <= (size_t)2 * (BM + BN) * kLdsStride * 4, "C tile must fit the operand LDS");
+  float* Cs = smem;
   const bool scale_on = (g.out_mul != 1.f) || (g.out_div != 1.f);
+  const bool vec_ok = g.vec_epilogue != 0;
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int ps = 0; ps < NPASS; ++ps) {
+    __syncthreads();   // operand buffers (or the previous pass) are no longer read
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (row >= g.M) continue;
-      // bilinear x2 (align_corners=True) taps of the half-resolution residual, per row
-      int p00 = 0, p01 = 0, p10 = 0, p11 = 0;
-      float wy1 = 0.f, wx1 = 0.f;
-      if (g.res_mode == OPP_RES_BILINEAR2X) {
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int jj = 0; jj < JP; ++jj) {
+        const int j = ps * JP + jj;
+        if (j < TN && tile_ok[j]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = acc[i][j][r];
+          }
+        }
+      }
+    __syncthreads();
+    for (int u = tid; u < BM * (WP / 4); u += NT) {
+      const int lr = u / (WP / 4);
+      const int lc = (u - lr * (WP / 4)) * 4;
+      const int wn2 = lc / (JP * 32);
+      const int j = ps * JP + (lc - wn2 * JP * 32) / 32;
+      const int row = m0 + lr;
+      const int col = n0 + wn2 * TN * 32 + j * 32 + (lc & 31);
+      if (j >= TN || (kRagged && wn2 * TN + j >= NT32) || row >= g.M || col >= g.n_store) continue;
+      const float4 cv = *reinterpret_cast<const float4*>(Cs + lr * CS + lc);
+      float v[4] = {cv.x, cv.y, cv.z, cv.w};
+      const int nval = g.n_store - col < 4 ? g.n_store - col : 4;   // < 4 only on the scalar path
+      if (scale_on) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] * g.out_mul) / g.out_div;
+      }
+      if (g.bias) {
+        if (vec_ok) {
+          const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
+          v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        } else {
+          for (int e = 0; e < nval; ++e) v[e] += g.bias[col + e];
+        }
+      }
+      if (g.res_mode == OPP_RES_DIRECT) {
+        const float* rp = g.R + (size_t)row * g.ldr + col;
+        if (vec_ok) {
+          const float4 rv = *reinterpret_cast<const float4*>(rp);
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        } else {
+          for (int e = 0; e < nval; ++e) v[e] += rp[e];
+        }
+      } else if (g.res_mode == OPP_RES_BILINEAR2X) {
+        // bilinear x2 (align_corners=True) taps of the half-resolution residual (resnet.py:151,155)
         const int ox = row % g.Wout;
         const int t = row / g.Wout;
         const int oy = t % g.Hout;
@@ -380,41 +431,57 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         if (x0 > g.Wr - 1) x0 = g.Wr - 1;
         const int y1 = y0 + (y0 < g.Hr - 1 ? 1 : 0);
         const int x1 = x0 + (x0 < g.Wr - 1 ? 1 : 0);
-        wy1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
-        wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+        const float wy1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
+        const float wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+        const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
         const int pb = b * g.Hr * g.Wr;
-        p00 = (pb + y0 * g.Wr + x0) * g.ldr;
-        p01 = (pb + y0 * g.Wr + x1) * g.ldr;
-        p10 = (pb + y1 * g.Wr + x0) * g.ldr;
-        p11 = (pb + y1 * g.Wr + x1) * g.ldr;
-      }
-      const float vdiv = row < g.split_row ? g.s0 : g.s1;
+        const float* r00 = g.R + (size_t)(pb + y0 * g.Wr + x0) * g.ldr + col;
+        const float* r01 = g.R + (size_t)(pb + y0 * g.Wr + x1) * g.ldr + col;
+        const float* r10 = g.R + (size_t)(pb + y1 * g.Wr + x0) * g.ldr + col;
+        const float* r11 = g.R + (size_t)(pb + y1 * g.Wr + x1) * g.ldr + col;
+        float a00[4], a01[4], a10[4], a11[4];
+        if (vec_ok) {
+          const float4 t0 = *reinterpret_cast<const float4*>(r00), t1 = *reinterpret_cast<const float4*>(r01);
+          const float4 t2 = *reinterpret_cast<const float4*>(r10), t3 = *reinterpret_cast<const float4*>(r11);
+          a00[0] = t0.x; a00[1] = t0.y; a00[2] = t0.z; a00[3] = t0.w;
+          a01[0] = t1.x; a01[1] = t1.y; a01[2] = t1.z; a01[3] = t1.w;
+          a10[0] = t2.x; a10[1] = t2.y; a10[2] = t2.z; a10[3] = t2.w;
+          a11[0] = t3.x; a11[1] = t3.y; a11[2] = t3.z; a11[3] = t3.w;
+        } else {
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = e < nval;
+            a00[e] = ok ? r00[e] : 0.f; a01[e] = ok ? r01[e] : 0.f;
+            a10[e] = ok ? r10[e] : 0.f; a11[e] = ok ? r11[e] : 0.f;
+          }
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 32 + j * 32 + l31;
-        if (!tile_ok[j] || col >= g.n_store) continue;
-        float v = acc[i][j][r];
-        if (scale_on) v = (v * g.out_mul) / g.out_div;
-        if (g.bias) v += g.bias[col];
-        if (g.res_mode == OPP_RES_DIRECT) {
-          v += g.R[(size_t)row * g.ldr + col];
-        } else if (g.res_mode == OPP_RES_BILINEAR2X) {
-          const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
-          const float top = wx0 * g.R[p00 + col] + wx1 * g.R[p01 + col];
-          const float bot = wx0 * g.R[p10 + col] + wx1 * g.R[p11 + col];
-          v += wy0 * top + wy1 * bot;
+        for (int e = 0; e < 4; ++e) {
+          const float top = wx0 * a00[e] + wx1 * a01[e];
+          const float bot = wx0 * a10[e] + wx1 * a11[e];
+          v[e] += wy0 * top + wy1 * bot;
         }
-        if (g.act == OPP_ACT_RELU) {
-          v = fmaxf(v, 0.f);
-        } else if (g.act == OPP_ACT_LEAKY) {
-          v = v > 0.f ? v : 0.01f * v;
-        } else if (g.act == OPP_ACT_QKV) {
-          if (col < g.qk_cols)
-            v = v > 0.f ? v + 1.f : expm1f(v) + 1.f;   // elu(x) + 1, linear_attention.py:10-11
-          else
-            v = v / vdiv;                               // values / v_length, linear_attention.py:55-56
+      }
+      if (g.act == OPP_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (g.act == OPP_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+      } else if (g.act == OPP_ACT_QKV) {
+        if (col < g.qk_cols) {   // elu(x) + 1 = x + 1 (x > 0) | exp(x) (x <= 0), linear_attention.py:10-11
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] + 1.f : __expf(v[e]);
+        } else {                 // values / v_length, linear_attention.py:55-56
+          const float vdiv = row < g.split_row ? g.s0 : g.s1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / vdiv;
         }
-        g.C[(size_t)row * g.ldc + col] = v;
+      }
+      float* cp = g.C + (size_t)row * g.ldc + col;
+      if (vec_ok) {
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int e = 0; e < nval; ++e) cp[e] = v[e];
       }
     }
   }
@@ -473,6 +540,12 @@ int launch_cfg(const OppGemm& g, hipStream_t stream) {
 
 int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   OppGemm g = g_in;
+  {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool v = g.n_store % 4 == 0 && g.ldc % 4 == 0 && al16(g.C) && (!g.bias || al16(g.bias)) && g.qk_cols % 4 == 0;
+    if (g.res_mode != OPP_RES_NONE) v = v && g.ldr % 4 == 0 && al16(g.R);
+    g.vec_epilogue = v ? 1 : 0;
+  }
   static const int xcd_env = getenv("OPP_XCD_SWIZZLE") ? atoi(getenv("OPP_XCD_SWIZZLE")) : 1;
   g.xcd_swizzle = xcd_env;
   OPP_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm: bad M/N/K (%d,%d,%d)", g.M, g.N, g.K);

@@ -82,6 +82,7 @@ struct OppGemm {
   // operand extents in bytes for the buffer descriptors (filled by the launcher)
   unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;
   int xcd_swizzle = 1;
+  int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
   // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
   double alg_flops = 0.0;
 };

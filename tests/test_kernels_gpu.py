@@ -11,7 +11,8 @@ def _bound(A, W):
     return (A.abs().double() @ W.abs().double().T).float()
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (1000, 64, 128), (77, 256, 96)])
+@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (1000, 64, 128), (77, 256, 96),
+                                   (50, 64, 81), (33, 96, 7)])
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
 def test_linear_tiles(M, K, N, cfg):
     from tests import hip_ops as ops
