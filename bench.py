@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-DOMINANT_CFG, DOMINANT_CONV = 0, 1
-DOMINANT_NAME = "opp_gemm_kernel<128,128,2,2,conv> (fp32 MFMA implicit-GEMM 3x3 conv)"
+DOMINANT_CFG, DOMINANT_CONV = 11, 1
+DOMINANT_NAME = "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)"
 
 
 def main():
@@ -66,18 +66,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = default_config(thr=args.thr, fine=args.fine)
     model = OnePosePlus_model(cfg).eval()
     sd = make_state_dict(cfg, 0) if rank == 0 else None
     model = model.to(dev)
-    if world > 1:
+    if dist is not None:
         from onepose_plus_plus_amd.sharding import broadcast_weights
-        broadcast_weights(model, sd, src=0)
+        broadcast_weights(model, sd, src=0)       # ONE broadcast of the flat weight buffer (RCCL over xGMI)
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
@@ -158,9 +160,14 @@ def main():
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
         if n.value > 0 and ms.value > 0:
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
+            if os.path.exists(tpath):     # HBM bytes per launch from the committed rocprofv3 --pmc passes
+                with open(tpath) as f:
+                    traffic = json.load(f)
             ach = fl.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": DOMINANT_NAME,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": DOMINANT_NAME,
                     "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "alg_gflop_per_launch": round(fl.value / n.value / 1e9, 3)}
     if dist is not None:

@@ -646,6 +646,7 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
                       float* mkpts_3d, int* count, Arena& a, hipStream_t s) {
   const int C = c->cfg.coarse_d_model, L = hc * wc;
   float* scratch = a.f(opp_coarse_match_scratch_floats(n, L));
+  float* stats = a.f(opp_coarse_match_stats_floats(n, L));
   if (!a.ok) {
     opp_set_error("coarse_match: workspace too small");
     return OPP_ERR_WORKSPACE;
@@ -666,8 +667,15 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   g.n_store = L;
   g.out_mul = 1.0f / (float)C;
   g.out_div = (float)((double)c->cfg.match_temperature + 1e-4);
-  OPP_TRY(opp_gemm_launch(g, s));
-  return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, scratch, i_ids, j_ids,
+  {  // dual-softmax (max, sum exp) partials fused into the epilogue: [n][tn] x2, [tm][L] x2
+    const size_t tn = opp_cdiv(L, 128), tm = opp_cdiv(n, 128);
+    g.stat_rowmax = stats;
+    g.stat_rowsum = g.stat_rowmax + (size_t)n * tn;
+    g.stat_colmax = g.stat_rowsum + (size_t)n * tn;
+    g.stat_colsum = g.stat_colmax + tm * (size_t)L;
+  }
+  OPP_TRY(opp_gemm_launch_cfg(g, 0, s));   // 128x128 tiles: the partial layout above assumes them
+  return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, stats, scratch, i_ids, j_ids,
                                  mconf, mkpts_c, mkpts_3d, count, s);
 }
 
@@ -675,7 +683,8 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
 
 extern "C" size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n, int L) {
   (void)ctx;
-  return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) + 512;
+  return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) +
+         opp_align(opp_coarse_match_stats_floats(n, L) * sizeof(float)) + 1024;
 }
 
 extern "C" int opp_coarse_match(opp_ctx* ctx, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts,

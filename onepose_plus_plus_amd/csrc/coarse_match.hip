@@ -108,6 +108,31 @@ __global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, in
   out[col] = acc;
 }
 
+// ---- merge of the per-tile (max, sum exp) partials produced by the score GEMM epilogue -----------
+// rows: part [N][T] ; cols: part [T][L] ; out max / sum with the global max as reference
+__global__ void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
+                                 float* __restrict__ omax, float* __restrict__ osum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float m = -INFINITY;
+  for (int t = 0; t < T; ++t) m = fmaxf(m, pmax[(size_t)i * T + t]);
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += psum[(size_t)i * T + t] * expf(pmax[(size_t)i * T + t] - m);
+  omax[i] = m;
+  osum[i] = s;
+}
+__global__ void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
+                                 float* __restrict__ omax, float* __restrict__ osum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L) return;
+  float m = -INFINITY;
+  for (int t = 0; t < T; ++t) m = fmaxf(m, pmax[(size_t)t * L + j]);
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += psum[(size_t)t * L + j] * expf(pmax[(size_t)t * L + j] - m);
+  omax[j] = m;
+  osum[j] = s;
+}
+
 // ---- conf = colsoftmax * rowsoftmax, in place; per-row max / first argmax / tie count --------
 template <int VEC>
 __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N, int L,
@@ -241,6 +266,12 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 
 }  // namespace
 
+// partial statistics written by the score GEMM epilogue (128x128 tiles)
+size_t opp_coarse_match_stats_floats(int N, int L) {
+  const size_t tn = opp_cdiv(L, 128), tm = opp_cdiv(N, 128);
+  return 2 * ((size_t)N * tn + tm * (size_t)L) + 16;
+}
+
 size_t opp_coarse_match_scratch_floats(int N, int L) {
   const int chunks = opp_cdiv(N, 128);
   const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
@@ -250,7 +281,7 @@ size_t opp_coarse_match_scratch_floats(int N, int L) {
 
 // S (in: similarity, out: confidence matrix) [N][L].  Outputs have capacity N.
 int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts, float base_scale,
-                            const float* qscale, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
+                            const float* qscale, const float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
                             float* mkpts_3d, int* count, hipStream_t stream) {
   OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0, "coarse match: bad sizes N=%d L=%d wc=%d", N, L, wc);
   const int chunks = opp_cdiv(N, 128);
@@ -267,12 +298,22 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   const bool vec4 = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cmax) & 15) == 0);
   dim3 rgrid(opp_cdiv(N, 4)), cgrid(opp_cdiv(L, 256), chunks), lgrid(opp_cdiv(L, 256));
 
-  if (vec4) hipLaunchKernelGGL(row_stats_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
-  else hipLaunchKernelGGL(row_stats_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
-  hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
-  hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, cmax);
-  hipLaunchKernelGGL(col_partial_kernel<1>, cgrid, dim3(256), 0, stream, S, N, L, 128, cmax, part);
-  hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum);
+  if (stats) {   // (max, sum exp) partials already produced by the score GEMM epilogue
+    const int tn = opp_cdiv(L, 128), tm = opp_cdiv(N, 128);
+    const float* rpm = stats;
+    const float* rps = rpm + (size_t)N * tn;
+    const float* cpm = rps + (size_t)N * tn;
+    const float* cps = cpm + (size_t)tm * L;
+    hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(N, 256)), dim3(256), 0, stream, rpm, rps, N, tn, rmax, rsum);
+    hipLaunchKernelGGL(col_merge_kernel, lgrid, dim3(256), 0, stream, cpm, cps, L, tm, cmax, csum);
+  } else {
+    if (vec4) hipLaunchKernelGGL(row_stats_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
+    else hipLaunchKernelGGL(row_stats_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
+    hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, cmax);
+    hipLaunchKernelGGL(col_partial_kernel<1>, cgrid, dim3(256), 0, stream, S, N, L, 128, cmax, part);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum);
+  }
   if (vec4) hipLaunchKernelGGL(conf_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
   else hipLaunchKernelGGL(conf_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
   hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);

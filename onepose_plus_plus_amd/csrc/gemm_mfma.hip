@@ -381,11 +381,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int lr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = acc[i][j][r];
+            const float cv0 = acc[i][j][r];
+            Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
           }
         }
       }
     __syncthreads();
+    if (g.stat_rowmax != nullptr && NPASS == 1 && !kRagged) {
+      // fused dual-softmax statistics (coarse_matching.py:115): partial (max, sum exp) of this
+      // tile per row (over its columns) and per column (over its rows); merged by tiny kernels
+      const int tiles_m_all = (g.M + BM - 1) / BM;
+      (void)tiles_m_all;
+      const int ncols = min(WP, g.n_store - n0);
+      const int nrows = min(BM, g.M - m0);
+      for (int lr = wave; lr < nrows; lr += WAVES_M * WAVES_N) {
+        float mx = -INFINITY;
+        for (int c = lane; c < ncols; c += 64) mx = fmaxf(mx, Cs[lr * CS + c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sm = 0.f;
+        for (int c = lane; c < ncols; c += 64) sm += expf(Cs[lr * CS + c] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        if (lane == 0) {
+          g.stat_rowmax[(size_t)(m0 + lr) * tiles_n + tile_n] = mx;
+          g.stat_rowsum[(size_t)(m0 + lr) * tiles_n + tile_n] = sm;
+        }
+      }
+      for (int c = tid; c < ncols; c += NT) {
+        float mx = -INFINITY;
+        for (int lr = 0; lr < nrows; ++lr) mx = fmaxf(mx, Cs[lr * CS + c]);
+        float sm = 0.f;
+        for (int lr = 0; lr < nrows; ++lr) sm += expf(Cs[lr * CS + c] - mx);
+        g.stat_colmax[(size_t)tile_m * g.n_store + n0 + c] = mx;
+        g.stat_colsum[(size_t)tile_m * g.n_store + n0 + c] = sm;
+      }
+    }
     for (int u = tid; u < BM * (WP / 4); u += NT) {
       const int lr = u / (WP / 4);
       const int lc = (u - lr * (WP / 4)) * 4;
@@ -397,10 +428,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       const float4 cv = *reinterpret_cast<const float4*>(Cs + lr * CS + lc);
       float v[4] = {cv.x, cv.y, cv.z, cv.w};
       const int nval = g.n_store - col < 4 ? g.n_store - col : 4;   // < 4 only on the scalar path
-      if (scale_on) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (v[e] * g.out_mul) / g.out_div;
-      }
       if (g.bias) {
         if (vec_ok) {
           const float4 bv = *reinterpret_cast<const float4*>(g.bias + col);
@@ -580,6 +607,12 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       if (t0 >= 384) cfg = 0;
       else if (t1 >= 512) cfg = 1;
       else cfg = 2;
+    }
+    // prefetch depth: long-K convolutions keep 4 (128x128, one workgroup per CU) or 3 (128x224)
+    // chunks of global loads in flight (measured +8 % / +2 % over depth 2)
+    if (g.conv && g.K >= 768) {
+      if (cfg == 0) cfg = 11;
+      else if (cfg == 3) cfg = 13;
     }
   }
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);

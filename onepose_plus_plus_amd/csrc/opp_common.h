@@ -83,6 +83,12 @@ struct OppGemm {
   unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;
   int xcd_swizzle = 1;
   int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
+  // optional softmax statistics of the OUTPUT tile (score GEMM of the coarse matcher): per row
+  // and per column (max, sum exp(v - max)) over this tile; [M][tiles_n] and [tiles_m][n_store]
+  float* stat_rowmax = nullptr;
+  float* stat_rowsum = nullptr;
+  float* stat_colmax = nullptr;
+  float* stat_colsum = nullptr;
   // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
   double alg_flops = 0.0;
 };

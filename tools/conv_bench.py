@@ -15,7 +15,7 @@ from onepose_plus_plus_amd import _lib  # noqa: E402
 
 # name, Hin, Win, cin, cout, ks, stride, cfgs
 CONVS = [
-    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 106, 107, 101, 105, 102, 103]),
+    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 106, 107, 101, 105, 102, 103]),
     ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11]),
     ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 13]),
     ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 15]),

@@ -1,0 +1,49 @@
+"""Per-kernel HBM traffic (bytes per launch) from the FETCH_SIZE / WRITE_SIZE passes of
+tools/pmc_bench.sh.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B:
+MI355X_MICROARCH.md §HBM); both counters are in KiB.
+
+    python tools/pmc_traffic_summary.py gpurun_out/pmc_bench profiles/r01_pmc_hbm_traffic.csv
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(d, out):
+    fetch = load(os.path.join(d, "FETCH_SIZE", "p_counter_collection.csv"))
+    write = load(os.path.join(d, "WRITE_SIZE", "p_counter_collection.csv"))
+    rows = []
+    for k in fetch:
+        f = sum(fetch[k]) / len(fetch[k]) * 1024 * 2
+        w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0]))) * 1024
+        rows.append((k, len(fetch[k]), f, w))
+    rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+    with open(out, "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["Kernel", "Launches", "FetchBytesPerLaunch(x2 corrected)", "WriteBytesPerLaunch"])
+        for r in rows:
+            wr.writerow([r[0], r[1], "%.0f" % r[2], "%.0f" % r[3]])
+    dom = [r for r in rows if "opp_gemm_kernel<128, 128, 2, 2, true" in r[0]]
+    dom.sort(key=lambda r: -r[1])
+    if dom:
+        k, n, fb, wb = dom[0]
+        js = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+              "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
+              "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py; FETCH x2 gfx950 correction"}
+        with open(os.path.join(os.path.dirname(out), "traffic_dominant_kernel.json"), "w") as f:
+            json.dump(js, f)
+        print(js)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
