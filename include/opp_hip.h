@@ -84,6 +84,12 @@ int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float* pe, int L,
                       const float* bank_c, int n_points, float* tokens, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* The 3D-point half of the tokens above on its own: it depends only on the object (keypoints +
+ * coarse bank), not on the query image, so a caller that keeps the bank resident encodes it once
+ * per object and passes the result to opp_forward_coarse.  tokens3d [N][C]. */
+int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* bank_c, int n_points,
+                      float* tokens3d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* LocalFeatureTransformer.forward (loftr_module/transformer.py:133-171), in place on
  * tokens = [n_seg*len0 rows of stream "2D" ; n_seg*len1 rows of stream "3D"] x d_model.
  * which = 0: loftr_coarse, 1: loftr_fine. */
@@ -103,11 +109,12 @@ int opp_coarse_match(opp_ctx* ctx, const float* feat3d, const float* feat2d, int
                      void* stream);
 
 /* Whole coarse level in one call: backbone -> tokens -> loftr_coarse -> coarse matching
- * (OnePosePlusModel.py:116-167).  feat_f is kept for the fine stage. */
+ * (OnePosePlusModel.py:116-167).  feat_f is kept for the fine stage.  tokens3d_pre: optional
+ * result of opp_encode_points for this object (NULL = encode kpts/bank_c here). */
 size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, int W, int n_points);
 int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W, const float* pe,
-                       const float* kpts, const float* bank_c, int n_points, float base_scale,
-                       const float* query_scale, float* feat_f, float* conf, long long* i_ids,
+                       const float* kpts, const float* bank_c, const float* tokens3d_pre, int n_points,
+                       float base_scale, const float* query_scale, float* feat_f, float* conf, long long* i_ids,
                        long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d, int* count,
                        void* workspace, size_t workspace_bytes, void* stream);
 

@@ -57,7 +57,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "opp_forward_coarse_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
-    "opp_forward_coarse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_float,
+    "opp_encode_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_forward_coarse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_fine_workspace_bytes": (c_size_t, [c_void_p, c_int]),

@@ -480,14 +480,23 @@ extern "C" int opp_backbone(opp_ctx* ctx, const float* image, int H, int W, floa
 // ----------------------------------------------------------------------------------------
 namespace {
 
-int coarse_tokens_impl(opp_ctx* c, const float* feat_c, const float* pe, int L, const float* kpts, const float* bank_c,
-                       int n, float* tokens, Arena& a, hipStream_t s) {
+int encode_points_impl(opp_ctx* c, const float* kpts, const float* bank_c, int n, float* t3, Arena& a, hipStream_t s) {
   const int C = c->cfg.coarse_d_model;
-  float* stats = a.f(8);
-  if (!a.ok) {
-    opp_set_error("coarse_tokens: workspace too small");
-    return OPP_ERR_WORKSPACE;
+  if (c->cfg.kpt_enc_enable) {
+    float* stats = a.f(8);
+    if (!a.ok) {
+      opp_set_error("encode_points: workspace too small");
+      return OPP_ERR_WORKSPACE;
+    }
+    OPP_TRY(opp_kpt_stats(kpts, n, stats, s));               // utils/normalize.py:16-26
+    return opp_kpt_encode(kpts, stats, bank_c, n, c->kpt_wt, c->kpt_b, t3, C, s);
   }
+  return opp_bank_transpose(bank_c, n, C, t3, C, s);
+}
+
+int coarse_tokens_impl(opp_ctx* c, const float* feat_c, const float* pe, int L, const float* kpts, const float* bank_c,
+                       int n, const float* tokens3d_pre, float* tokens, Arena& a, hipStream_t s) {
+  const int C = c->cfg.coarse_d_model;
   if (pe) {
     OPP_TRY(opp_add(feat_c, pe, tokens, (size_t)L * C, s));   // OnePosePlusModel.py:137-142
   } else if (hipMemcpyAsync(tokens, feat_c, (size_t)L * C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -495,13 +504,14 @@ int coarse_tokens_impl(opp_ctx* c, const float* feat_c, const float* pe, int L, 
     return OPP_ERR_LAUNCH;
   }
   float* t3 = tokens + (size_t)L * C;
-  if (c->cfg.kpt_enc_enable) {
-    OPP_TRY(opp_kpt_stats(kpts, n, stats, s));               // utils/normalize.py:16-26
-    OPP_TRY(opp_kpt_encode(kpts, stats, bank_c, n, c->kpt_wt, c->kpt_b, t3, C, s));
-  } else {
-    OPP_TRY(opp_bank_transpose(bank_c, n, C, t3, C, s));
+  if (tokens3d_pre) {   // per-object constant, encoded once (opp_encode_points): just place it
+    if (hipMemcpyAsync(t3, tokens3d_pre, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      opp_set_error("coarse_tokens: copy of cached point tokens failed");
+      return OPP_ERR_LAUNCH;
+    }
+    return OPP_OK;
   }
-  return OPP_OK;
+  return encode_points_impl(c, kpts, bank_c, n, t3, a, s);
 }
 
 struct TrBufs {
@@ -614,7 +624,14 @@ extern "C" int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float*
   OPP_CHECK_ARG(ctx && ctx->packed && feat_c && kpts && bank_c && tokens && ws, "coarse_tokens: null argument");
   OPP_CHECK_ARG(L > 0 && n > 0, "coarse_tokens: empty input");
   Arena a(ws, ws_bytes);
-  return coarse_tokens_impl(ctx, feat_c, pe, L, kpts, bank_c, n, tokens, a, (hipStream_t)stream);
+  return coarse_tokens_impl(ctx, feat_c, pe, L, kpts, bank_c, n, nullptr, tokens, a, (hipStream_t)stream);
+}
+
+extern "C" int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* bank_c, int n, float* tokens3d, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ctx && ctx->packed && kpts && bank_c && tokens3d && ws && n > 0, "encode_points: bad argument");
+  Arena a(ws, ws_bytes);
+  return encode_points_impl(ctx, kpts, bank_c, n, tokens3d, a, (hipStream_t)stream);
 }
 
 extern "C" size_t opp_transformer_workspace_bytes(const opp_ctx* ctx, int which, int n_seg, int len0, int len1) {
@@ -728,10 +745,11 @@ extern "C" size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, 
 }
 
 extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W, const float* pe, const float* kpts,
-                                  const float* bank_c, int n, float base_scale, const float* qscale, float* feat_f, float* conf,
+                                  const float* bank_c, const float* tokens3d_pre, int n, float base_scale,
+                                  const float* qscale, float* feat_f, float* conf,
                                   long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d,
                                   int* count, void* ws, size_t ws_bytes, void* stream) {
-  OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && bank_c && feat_f && conf && ws, "forward_coarse: null argument");
+  OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && (bank_c || tokens3d_pre) && feat_f && conf && ws, "forward_coarse: null argument");
   OPP_CHECK_ARG(n > 0, "forward_coarse: empty point cloud");
   OPP_CHECK_ARG(!ctx->cfg.pos_enc_enable || pe, "forward_coarse: positional encoding enabled but pe is null");
   hipStream_t s = (hipStream_t)stream;
@@ -746,7 +764,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   const int hc = H / 8, wc = W / 8, L = hc * wc, C = ctx->cfg.coarse_d_model;
   OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
   a.off = mark;
-  OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens, a, s));
+  OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;
   OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s));
   a.off = mark;

@@ -34,32 +34,48 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ res, int ldres,
                                                         float* __restrict__ out, int ldo, int rows,
                                                         float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  constexpr int RPW = 4;   // rows per wave: all loads issued before the first reduction
   constexpr int C = 64 * VPT;
-  float v[VPT];
-  const float* xr = x + (size_t)row * ldx + lane * VPT;
-#pragma unroll
-  for (int i = 0; i < VPT; ++i) v[i] = xr[i];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < VPT; ++i) s += v[i];
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  float v[RPW][VPT], rv[RPW][VPT], gm[VPT], bt[VPT];
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const float d = v[i] - mean;
-    q += d * d;
+    gm[i] = gamma[lane * VPT + i];
+    bt[i] = beta[lane * VPT + i];
   }
-  const float var = wave_sum(q) / (float)C;
-  const float rstd = 1.0f / sqrtf(var + eps);
-  float* orow = out + (size_t)row * ldo + lane * VPT;
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
-    float y = (v[i] - mean) * rstd * gamma[lane * VPT + i] + beta[lane * VPT + i];
-    if (res) y = res[(size_t)row * ldres + lane * VPT + i] + y;
-    orow[i] = y;
+  for (int r = 0; r < RPW; ++r) {
+    const bool ok = row0 + r < rows;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      v[r][i] = ok ? x[(size_t)(row0 + r) * ldx + lane * VPT + i] : 0.f;
+      rv[r][i] = (ok && res) ? res[(size_t)(row0 + r) * ldres + lane * VPT + i] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    if (row0 + r >= rows) break;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) s += v[r][i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const float d = v[r][i] - mean;
+      q += d * d;
+    }
+    const float var = wave_sum(q) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* orow = out + (size_t)(row0 + r) * ldo + lane * VPT;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      float y = (v[r][i] - mean) * rstd * gm[i] + bt[i];
+      if (res) y = rv[r][i] + y;
+      orow[i] = y;
+    }
   }
 }
 
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __
 int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res,
                   int ldres, float* out, int ldo, int rows, int C, float eps, hipStream_t stream) {
   if (rows <= 0) return OPP_OK;
-  dim3 grid(opp_cdiv(rows, 4)), block(256);
+  dim3 grid(opp_cdiv(rows, 16)), block(256);
   if (C == 256)
     hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, res, ldres, out, ldo, rows, eps);
   else if (C == 128)

@@ -24,6 +24,7 @@
 //    scaling for the linear attention, temperature scaling for the score matrix.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include <vector>
@@ -522,6 +523,7 @@ struct GemmProfiler {
   size_t used = 0;              // events used
   double flops = 0.0;
   long long dropped = 0;
+  std::mutex mu;                // forwards may be in flight from several host threads / streams
 } g_prof;
 
 template <int ABL>
@@ -617,14 +619,19 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   }
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
+  size_t slot = 0;
   if (prof) {
-    if (g_prof.used + 2 <= g_prof.ev.size()) {
-      (void)hipEventRecord(g_prof.ev[g_prof.used], stream);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
+      slot = g_prof.used;
+      g_prof.used += 2;
+      g_prof.flops += g.alg_flops > 0.0 ? g.alg_flops : 2.0 * (double)g.M * (double)g.N * (double)g.K;
       rec = true;
     } else {
       g_prof.dropped++;
     }
   }
+  if (rec) (void)hipEventRecord(g_prof.ev[slot], stream);
   int rc;
   switch (cfg) {
     case 0: rc = launch_cfg<128, 128, 2, 2>(g, stream); break;
@@ -645,17 +652,14 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 107: rc = g.conv ? launch_ablate<7>(g, stream) : OPP_ERR_INVALID; break;
     default: opp_set_error("gemm: unknown tile config %d", cfg); return OPP_ERR_INVALID;
   }
-  if (rec) {
-    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], stream);
-    g_prof.used += 2;
-    g_prof.flops += g.alg_flops > 0.0 ? g.alg_flops : 2.0 * (double)g.M * (double)g.N * (double)g.K;
-  }
+  if (rec) (void)hipEventRecord(g_prof.ev[slot + 1], stream);
   return rc;
 }
 
 // Live measurement of one GEMM kernel symbol with HIP events recorded on the launch stream
 // (bench.py roofline leg).  start: arm for (tile_cfg, conv) with room for `capacity` launches.
 extern "C" int opp_profile_start(int tile_cfg, int conv, int capacity) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.clear();
   g_prof.ev.resize((size_t)capacity * 2);
@@ -676,6 +680,7 @@ extern "C" int opp_profile_start(int tile_cfg, int conv, int capacity) {
 // stop: synchronises the recorded events; returns summed kernel time (ms), summed algorithmic
 // FLOPs and the number of launches measured.
 extern "C" int opp_profile_stop(double* total_ms, double* total_flops, int* launches) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = false;
   double ms = 0.0;
   for (size_t i = 0; i + 1 < g_prof.used; i += 2) {

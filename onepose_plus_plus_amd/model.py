@@ -195,16 +195,19 @@ class OnePosePlus_model(nn.Module):
             self._rt["dirty"] = True
             self._rt["pe"] = {}
             self._rt["ws"] = None
+            self._rt["obj"] = None
         return out
 
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
         self._rt["dirty"] = True
+        self._rt["obj"] = None
         return out
 
     def repack(self):
         """Call after modifying parameters in place (packed weights are cached)."""
         self._rt["dirty"] = True
+        self._rt["obj"] = None
 
     # ---- C-ABI plumbing ------------------------------------------------------------------
     def _c_config(self):
@@ -283,6 +286,27 @@ class OnePosePlus_model(nn.Module):
             self._rt["pe"][key] = pe[0, :, :hc, :wc].permute(1, 2, 0).reshape(hc * wc, -1).contiguous().to(device)
         return self._rt["pe"][key]
 
+    def _object_tokens(self, lib, ctx, kpts, bank_c, device, stream):
+        """Encoded 3D-point tokens [N, C] of the current object.  They depend only on
+        (keypoints3d, coarse bank) -- OnePosePlusModel.py:144-156 recomputes them per image -- so
+        they are cached per object: the key is the identity AND version counter of both tensors
+        (an in-place edit or a different object re-encodes).  Set `cache_object_tokens = False`
+        to encode per image like the reference."""
+        if not getattr(self, "cache_object_tokens", True):
+            return None
+        src = (kpts, bank_c)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src)
+        hit = self._rt.get("obj")
+        if hit is not None and hit[0] == key and hit[1].device == device:
+            return hit[1]
+        n = int(kpts.shape[1])
+        tok = torch.empty((n, self.config["loftr_coarse"]["d_model"]), dtype=torch.float32, device=device)
+        ws = torch.empty(4096, dtype=torch.uint8, device=device)
+        _lib.check(lib.opp_encode_points(ctx, kpts.data_ptr(), bank_c.data_ptr(), n, tok.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), stream), "opp_encode_points")
+        self._rt["obj"] = (key, tok, src)     # keep the source tensors alive so the key cannot alias
+        return tok
+
     def _workspace(self, nbytes, device):
         ws = self._rt["ws"]
         if ws is None or ws.numel() < nbytes or ws.device != device:
@@ -353,9 +377,10 @@ class OnePosePlus_model(nn.Module):
             ws_bytes = lib.opp_forward_coarse_workspace_bytes(ctx, H, W, N)
             ws = self._workspace(ws_bytes, device)
             scale_c = float(H) / float(hc)                                               # coarse_matching.py:222
+            tok3d = self._object_tokens(lib, ctx, kpts, bank_c, device, stream)
             _lib.check(lib.opp_forward_coarse(
                 ctx, img_c.data_ptr(), H, W, pe.data_ptr() if pe is not None else None, kpts.data_ptr(),
-                bank_c.data_ptr(), N, scale_c, qscale.data_ptr() if qscale is not None else None,
+                bank_c.data_ptr(), tok3d.data_ptr() if tok3d is not None else None, N, scale_c, qscale.data_ptr() if qscale is not None else None,
                 feat_f.data_ptr(), conf.data_ptr(), i_ids.data_ptr(), j_ids.data_ptr(), mconf.data_ptr(),
                 mk_c.data_ptr(), mk_3d.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), stream),
                 "opp_forward_coarse")

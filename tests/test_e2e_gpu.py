@@ -86,3 +86,34 @@ def test_no_cpu_fallback():
     m = OnePosePlus_model(default_config()).eval()
     with pytest.raises(RuntimeError):
         m({"query_image": torch.zeros(1, 1, 64, 64)})
+
+
+def test_object_token_cache_is_transparent():
+    """The per-object cache of encoded 3D tokens must never change results: new object, same
+    object again, and an in-place edit of the bank all give what an uncached model gives."""
+    from tests import hip_ops as ops
+    cfg, sd, data_a = H.e2e_setup("e2e_128x128_n300_thr0")
+    data_b = H.e2e_setup("e2e_128x128_n300_thr0")[2]
+    g = torch.Generator().manual_seed(99)
+    data_b["descriptors3d_coarse_db"] = torch.randn(1, 256, 300, generator=g)
+    data_b["keypoints3d"] = torch.rand(1, 300, 3, generator=g) - 0.5
+    cached = ops.make_model(cfg, sd)
+    plain = ops.make_model(cfg, sd)
+    plain.cache_object_tokens = False
+    da = {k: v.cuda() for k, v in data_a.items()}
+    db = {k: v.cuda() for k, v in data_b.items()}
+
+    def run(m, d):
+        d = dict(d)
+        with torch.no_grad():
+            m(d)
+        torch.cuda.synchronize()
+        return d
+
+    for d in (da, db, da, da):
+        o1, o2 = run(cached, d), run(plain, d)
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f"):
+            assert torch.equal(o1[k], o2[k]), k
+    da["descriptors3d_coarse_db"].mul_(0.5)          # in-place edit -> version bump -> re-encode
+    o1, o2 = run(cached, da), run(plain, da)
+    assert torch.equal(o1["conf_matrix"], o2["conf_matrix"])
