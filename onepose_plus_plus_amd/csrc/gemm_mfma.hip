@@ -136,19 +136,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   };
 
   // wave-uniform K-chunk cursor of the global prefetch (no per-chunk integer division).
-  //
-  // The K chunks are visited in a ROTATED order that differs from workgroup to workgroup:
-  // every workgroup walks the chunks in lockstep, and chunk k of every row lives at the same
-  // offset inside the (512 B .. 3 KB) row record, i.e. on the same few L2 channels.  With all
-  // 512 workgroups on the same chunk the activation loads were served by a quarter of the
-  // channels (measured: ~3.3 TB/s cap, 15-25 % of the kernel in vmcnt waits).  Starting
-  // workgroup t at chunk (t mod n) spreads the accesses over all channels; the sum over k is
-  // order-independent, and the order is a fixed function of the tile index (deterministic).
+  // Every tile walks K in the same order, so equal operands give bit-equal results in every
+  // tile (exact ties in the confidence matrix behave like the reference's).  A per-workgroup
+  // rotation of the chunk order (to spread L2 channels) was measured and gave nothing.
   const int nk = g.K / 32;
   const int taps = CONV ? g.ksize * g.ksize : 1;
   const int ngrp = CONV ? g.Cin / 32 : nk;            // rotation period: channel groups / chunks
   int cur_i = 0;                                      // chunks issued so far
-  int cur_grp = (tile_m + tile_n) % ngrp;             // channel group (conv) or chunk index (dense)
+  int cur_grp = 0;                                    // channel group (conv) or chunk index (dense)
   int cur_tap = 0, cur_ky = 0, cur_kx = 0;
   int cur_k0 = CONV ? cur_grp * taps * 32 : cur_grp * 32;
   unsigned cur_delta = CONV ? (unsigned)(cur_grp * 32) * 4u : 0u;
@@ -491,7 +486,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       }
       if (g.act == OPP_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];   // NaN-propagating like torch.relu
       } else if (g.act == OPP_ACT_LEAKY) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
@@ -598,24 +593,17 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     OPP_CHECK_ARG(g.res_mode != OPP_RES_BILINEAR2X, "gemm: bilinear residual needs conv mode");
   }
   if (cfg < 0) {
-    // Tile choice from the MI355X micro-bench (tools/conv_bench.py): 256 CUs, 4 SIMDs each.
-    if (g.n_store % 224 == 0) {
-      // 196(->224)-channel stages: 128x224 (4 waves x 32x224) when M fills >= 2 rounds of CUs,
-      // else 64x224 with the columns split 128 + 96 over two wave columns (all 4 SIMDs busy)
-      cfg = (opp_cdiv(g.M, 128) * (g.n_store / 224) >= 384) ? 3 : 5;
-    } else {
-      const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
-      const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
-      if (t0 >= 384) cfg = 0;
-      else if (t1 >= 512) cfg = 1;
-      else cfg = 2;
-    }
-    // prefetch depth: long-K convolutions keep 4 (128x128, one workgroup per CU) or 3 (128x224)
-    // chunks of global loads in flight (measured +8 % / +2 % over depth 2)
-    if (g.conv && g.K >= 768) {
-      if (cfg == 0) cfg = 11;
-      else if (cfg == 3) cfg = 13;
-    }
+    // Tile choice from the MI355X micro-bench (tools/conv_bench.py; 256 CUs x 4 SIMDs).  The
+    // 196(->224)-channel stages run as two column tiles (128 + 96 real columns): measured 4-12 %
+    // faster than the dedicated 128x224 / 64x224 tiles, which stay available as explicit configs.
+    const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
+    const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
+    if (t0 >= 384) cfg = 0;
+    else if (t1 >= 512) cfg = 1;
+    else cfg = 2;
+    // prefetch depth of the long-K convolutions on 128x128 tiles: 4 register sets when the grid
+    // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
+    if (g.conv && g.K >= 768 && cfg == 0) cfg = t0 <= 512 ? 11 : 10;
   }
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
@@ -638,12 +626,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 1: rc = launch_cfg<64, 128, 2, 2>(g, stream); break;
     case 2: rc = launch_cfg<64, 64, 2, 2>(g, stream); break;
     case 3: rc = launch_cfg<128, 224, 4, 1>(g, stream); break;
-    case 4: rc = launch_cfg<64, 224, 2, 1>(g, stream); break;
     case 5: rc = launch_cfg<64, 224, 2, 2>(g, stream); break;   // 4 waves: N split 128 + 96
     case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // prefetch depth experiments
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
-    case 13: rc = launch_cfg<128, 224, 4, 1, 3>(g, stream); break;
-    case 15: rc = launch_cfg<64, 224, 2, 2, 3>(g, stream); break;
     case 101: rc = g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID; break;
     case 102: rc = g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID; break;
     case 103: rc = g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID; break;

@@ -109,7 +109,10 @@ __device__ __forceinline__ void point_norm_relu(float* __restrict__ buf, int str
     }
     const float var = wave_sum_k(q) / (float)C;
     const float rstd = 1.0f / sqrtf(var + eps);
-    for (int c = lane; c < C; c += 64) row[c] = fmaxf((row[c] - mean) * rstd, 0.f);
+    for (int c = lane; c < C; c += 64) {
+      const float y = (row[c] - mean) * rstd;
+      row[c] = y < 0.f ? 0.f : y;   // ReLU that propagates NaN like torch (a zero-extent cloud gives NaN upstream)
+    }
   }
 }
 

@@ -26,7 +26,7 @@ def test_linear_tiles(M, K, N, cfg):
     assert (err <= 2e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
 
 
-@pytest.mark.parametrize("cfg", [3, 4, 5, -1])
+@pytest.mark.parametrize("cfg", [3, 5, 10, 11, -1])
 @pytest.mark.parametrize("N", [224, 448])
 def test_linear_224_tiles(cfg, N):
     from tests import hip_ops as ops
@@ -64,7 +64,7 @@ CONV_CASES = [
 def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
     from tests import hip_ops as ops
     if cout == 196 and cfg != -1:
-        cfg = {0: 3, 2: 4, 1: 5}[cfg]
+        cfg = {0: 3, 2: 5, 1: 11}[cfg]
     g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
     x = torch.randn(1, cin, H, W, generator=g)
     w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5

@@ -94,3 +94,61 @@ def test_fine_vs_golden(small, name):
     gold = H.load_golden(name)
     H.assert_match_outputs({"expec_f": ex, "mkpts_query_f": mf}, {k: gold[k] for k in ("expec_f", "mkpts_query_f")},
                            where=name)
+
+
+def test_matcher_exact_ties_follow_reference_rules():
+    """Duplicated image cells (tie inside a row -> first column wins) and duplicated 3D points
+    (both rows are reported with the same cell), coarse_matching.py:158-172 / quirk q9."""
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    cfg = default_config(thr=0.05)
+    g = torch.Generator().manual_seed(42)
+    hw_c = (16, 24)
+    L, N = hw_c[0] * hw_c[1], 300
+    f2d = torch.randn(L, 256, generator=g) * 4
+    f3d = torch.randn(N, 256, generator=g) * 4
+    a, b = 2 * 24 + 5, 9 * 24 + 7          # two interior cells made identical: point 0 matches both
+    perm = [c for c in torch.randperm(L, generator=g).tolist() if c not in (a, b)]
+    cells = torch.tensor(perm[:200])
+    f3d[:200] = f2d[cells] + 0.4 * torch.randn(200, 256, generator=g)
+    f2d[b] = f2d[a]
+    f3d[0] = f2d[a] + 0.4 * torch.randn(256, generator=g)
+    f3d[150] = f3d[149]                     # duplicated 3D point (same tile)
+    f3d[290] = f3d[10]                      # duplicated 3D point (different 128-row tile)
+    kpts = torch.rand(1, N, 3, generator=g) - 0.5
+    data = {"q_hw_i": torch.Size([128, 192]), "q_hw_c": torch.Size(hw_c), "keypoints3d": kpts}
+    O.coarse_matching(f3d[None], f2d[None], data, cfg["coarse_matching"])
+    model = ops.make_model(cfg, make_state_dict(cfg, 0))
+    got = ops.coarse_match(model, f3d, f2d, hw_c, kpts[0], 8.0, None)
+    ref_i, ref_j = data["i_ids"].tolist(), data["j_ids"].tolist()
+    assert 0 in ref_i and ref_j[ref_i.index(0)] == min(a, b)          # the tie resolves to the first cell
+    assert got["i_ids"].tolist() == ref_i and got["j_ids"].tolist() == ref_j
+    assert (got["mconf"] - data["mconf"]).abs().max() < 1e-4
+    c = got["conf_matrix"][0]
+    assert torch.equal(c[:, a], c[:, b]) and torch.equal(c[150], c[149]) and torch.equal(c[290], c[10])
+
+
+@pytest.mark.parametrize("hw,n", [((16, 24), 5), ((8, 8), 3), ((24, 16), 1), ((64, 64), 129)])
+def test_tiny_shapes_vs_oracle(hw, n):
+    """Degenerate sizes: a 1-cell coarse grid, a single 3D point, N just over one tile."""
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    cfg = default_config(thr=0.0)
+    cfg["coarse_matching"]["border_rm"] = 0
+    sd = make_state_dict(cfg, 3)
+    data = make_inputs(n, hw, 21)
+    ref = dict(data)
+    O.forward(sd, ref, cfg)
+    out = ops.run_model(ops.make_model(cfg, sd), data)
+    assert out["i_ids"].tolist() == ref["i_ids"].tolist() and out["j_ids"].tolist() == ref["j_ids"].tolist()
+    if n == 1:   # zero bbox extent: normalize_3d_keypoints divides 0/0 upstream -> NaN everywhere, no match
+        assert torch.isnan(ref["conf_matrix"]).all() and torch.isnan(out["conf_matrix"]).all()
+        return
+    assert (out["conf_matrix"].cpu() - ref["conf_matrix"]).abs().max() < 1e-4
+    if len(ref["mconf"]):
+        assert (out["expec_f"].cpu() - ref["expec_f"]).abs().max() < 1e-4
+        assert (out["mkpts_query_f"].cpu() - ref["mkpts_query_f"]).abs().max() < 1e-3

@@ -17,9 +17,10 @@ from onepose_plus_plus_amd import _lib  # noqa: E402
 CONVS = [
     ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 106, 107, 101, 105, 102, 103]),
     ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11]),
-    ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 13]),
-    ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 15]),
-    ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [4, 5]),
+    ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 11, 10]),
+    ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 1, 2]),
+    ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [5, 1, 2]),
+    ("l2_out2b 3x3 256->196 @128", 128, 128, 256, 196, 3, 1, [5, 1, 2]),
     ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1, [1, 0, 2]),
     ("layer3 3x3 256->256 @64", 64, 64, 256, 256, 3, 1, [2, 1]),
 ]
@@ -74,8 +75,6 @@ def main():
             if cfg in (3, 4, 5, 13, 15) and cop % 224:
                 continue
             if cfg >= 100 and not os.environ.get("OPP_ABLATE"):
-                continue
-            if cfg in (0, 1, 2, 10, 11) and cop % 224 == 0:
                 continue
 
             def fn():

@@ -37,7 +37,7 @@ def t_linear():
         g = torch.Generator().manual_seed(1)
         A, W = torch.randn(300, 256, generator=g), torch.randn(768, 256, generator=g)
         stat("linear cfg%d" % cfg, ops.linear(A, W, 0, cfg), (A.double() @ W.double().T).float())
-    for cfg in (3, 4):
+    for cfg in (3, 5):
         g = torch.Generator().manual_seed(2)
         A, W = torch.randn(333, 96, generator=g), torch.randn(224, 96, generator=g)
         stat("linear224 cfg%d" % cfg, ops.linear(A, W, 0, cfg), (A.double() @ W.double().T).float())
