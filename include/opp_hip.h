@@ -145,6 +145,19 @@ int opp_linear(const float* A, int M, int K, const float* W, int N, int act, flo
 int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
                    float* out, int rows, int C, void* stream);
 
+/* ---- pose from the matches (next row after the matcher) --------------------
+ * PnP-RANSAC on the device: replaces ransac_PnP / cv2.solvePnPRansac(EPNP, 10000 iterations)
+ * (src/utils/metric_utils.py:121-204) so the matches never leave the GPU.  pts2d [n][2] (pixels),
+ * pts3d [n][3] fp32 on the device; K4 = {fx, fy, cx, cy} on the HOST; `scale` multiplies the 3D
+ * points before solving and divides the translation after (reference `point_cloud_rescale`).
+ * Outputs on the device: pose_out [12] doubles = row-major [R | t] (3x4), inlier_mask [n] (0/1),
+ * n_inliers, ok (0 -> identity pose, the reference's cv2.error branch).  Deterministic for a seed. */
+size_t opp_pnp_workspace_bytes(int iterations);
+int opp_pnp_ransac(const float* pts2d, const float* pts3d, int n_points, const double* K4,
+                   double reproj_error_px, double scale, int iterations, unsigned seed,
+                   int refine_iters, double* pose_out, int* inlier_mask, int* n_inliers, int* ok,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- live kernel timing for bench.py's roofline leg ---------------------------------------
  * Arms HIP-event timing (events recorded on the launch stream) of every launch of one GEMM /
  * implicit-conv kernel symbol: tile_cfg 0..4 (128x128, 64x128, 64x64, 128x224, 64x224), conv 1/0.

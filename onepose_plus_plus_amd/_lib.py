@@ -69,6 +69,10 @@ SIGNATURES = {
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "opp_pnp_workspace_bytes": (c_size_t, [c_int]),
+    "opp_pnp_ransac": (c_int, [c_void_p, c_void_p, c_int, POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double,
+                               c_int, ctypes.c_uint, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_size_t, c_void_p]),
     "opp_profile_start": (c_int, [c_int, c_int, c_int]),
     "opp_profile_stop": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
 }
