@@ -117,3 +117,20 @@ def test_object_token_cache_is_transparent():
     da["descriptors3d_coarse_db"].mul_(0.5)          # in-place edit -> version bump -> re-encode
     o1, o2 = run(cached, da), run(plain, da)
     assert torch.equal(o1["conf_matrix"], o2["conf_matrix"])
+
+
+def test_matcher_pool_matches_sequential():
+    """n forwards in flight on separate HIP streams give exactly the sequential results, in order."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.serving import MatcherPool
+    from onepose_plus_plus_amd.synthetic import make_inputs
+    cfg, sd, _ = H.e2e_setup("e2e_128x128_n300_thr0")
+    seq_model = ops.make_model(cfg, sd)
+    datas = [make_inputs(300, (128, 128), 50 + i) for i in range(7)]
+    ref = [ops.run_model(seq_model, d) for d in datas]
+    pool = MatcherPool(cfg, sd, n_streams=3)
+    got = pool.map([{k: v.cuda() for k, v in d.items()} for d in datas])
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+            assert torch.equal(r[k], g[k]), k
