@@ -48,6 +48,11 @@ typedef struct opp_config {
   float match_thr;         /* coarse_matching.thr */
   int match_border_rm;     /* coarse_matching.border_rm */
   float match_temperature; /* coarse_matching.dual_softmax.temperature */
+  /* Not a reference key: arithmetic of the conv / Linear GEMMs.  0 = fp32 MFMA (exact fp32).
+   * 1 = fp16x2 split: every operand x is carried as hi = fp16(x), lo = fp16(x - hi) (22-bit mantissa),
+   * three fp16 MFMAs per product (hi*lo + lo*hi + hi*hi) with fp32 accumulation, 3/16 of the fp32
+   * MFMA cycles.  The coarse score GEMM always runs in fp32 (its error is amplified 12.5x). */
+  int gemm_precision;
 } opp_config;
 
 typedef struct opp_ctx opp_ctx;
@@ -133,15 +138,23 @@ int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* ban
  * [cout_pad][ks*ks*cin_pad] (from opp_pack_conv_weight); bias [cout_pad] or NULL; residual:
  * res_mode 0 none, 1 same-shape NHWC [Hout][Wout][cout_pad], 2 bilinear x2 (align_corners)
  * upsample of NHWC [Hout/2][Wout/2][cout_pad]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
- * tile_cfg < 0 selects automatically. */
+ * tile_cfg < 0 selects automatically.  h2 = 1: w_packed was additionally pre-split (opp_pack_h2);
+ * h2_scale = the scale2 pointer given to opp_pack_h2, or NULL. */
 int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed,
                     const float* bias, int cout_pad, int ks, int stride, const float* residual,
-                    int res_mode, int act, float* y, int tile_cfg, void* stream);
+                    int res_mode, int act, float* y, int tile_cfg, int h2, const float* h2_scale,
+                    void* stream);
 int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks,
                          int cout_pad, int cin_pad, float* out, void* stream);
-/* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU */
+/* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  h2 = 1: W was pre-split by
+ * opp_pack_h2 and the fp16x2 kernel is used (tile_cfg 0, 1, 2, 10, 11 or < 0). */
 int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,
-               int tile_cfg, void* stream);
+               int tile_cfg, int h2, const float* h2_scale, void* stream);
+/* fp16x2 pre-split of a K-contiguous weight matrix (n floats, n % 8 == 0, out != in, same size).
+ * scale2 (device, 2 floats, may be NULL): receives {s, 1/s}, s the power of two that brings max|w|
+ * into [2^14, 2^15) and is applied before the split; pass the same pointer as h2_scale to
+ * opp_linear / opp_conv2d_nhwc, which multiply the accumulators by 1/s (exact). */
+int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream);
 int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
                    float* out, int rows, int C, void* stream);
 

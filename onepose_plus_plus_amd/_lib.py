@@ -31,6 +31,7 @@ class OppConfig(Structure):
         ("match_thr", c_float),
         ("match_border_rm", c_int),
         ("match_temperature", c_float),
+        ("gemm_precision", c_int),
     ]
 
 
@@ -65,9 +66,10 @@ SIGNATURES = {
     "opp_fine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
-                                c_int, c_int, c_void_p, c_int, c_void_p]),
+                                c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "opp_pack_h2": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "opp_pnp_workspace_bytes": (c_size_t, [c_int]),
     "opp_pnp_ransac": (c_int, [c_void_p, c_void_p, c_int, POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double,

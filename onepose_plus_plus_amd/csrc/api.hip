@@ -41,6 +41,7 @@ struct ConvDesc {  // one packed convolution
   int cin = 0, cout = 0, ks = 1;
   float* w = nullptr;     // packed [cout_pad][ks*ks*cin_pad]
   float* bias = nullptr;  // [cout_pad] (folded BN shift) or nullptr
+  float* h2s = nullptr;   // fp16x2 only: {scale, 1/scale} applied to w before the hi/lo split
   int cin_pad() const { return pad32(cin); }
   int cout_pad() const { return pad32(cout); }
   size_t w_floats() const { return (size_t)cout_pad() * ks * ks * cin_pad(); }
@@ -55,6 +56,7 @@ struct EncLayerDesc {
   int q_idx = -1;  // q,k,v,merge,mlp0,mlp2,norm1.w,norm1.b,norm2.w,norm2.b follow consecutively
   float *wqkv = nullptr, *wmerge = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  float *sqkv = nullptr, *smerge = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp16x2 {scale, 1/scale} per matrix
 };
 
 }  // namespace
@@ -75,6 +77,7 @@ struct opp_ctx {
   bool packed = false;
   size_t packed_bytes = 0;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
+  float* scratch_h2 = nullptr;     // fp16x2 pre-split staging (largest weight matrix)
 };
 
 namespace {
@@ -228,9 +231,20 @@ std::vector<ConvDesc*> all_convs(opp_ctx* c) {
 size_t plan_pack(opp_ctx* c, void* base) {
   Arena a(base, (size_t)-1);
   c->scratch_scale = a.f(256);
+  {
+    size_t mx = (size_t)c->stem.cout * 64;
+    for (ConvDesc* d : all_convs(c)) mx = d->w_floats() > mx ? d->w_floats() : mx;
+    const size_t dc = c->cfg.coarse_d_model, df = c->cfg.fine_d_model;
+    mx = 4 * dc * dc > mx ? 4 * dc * dc : mx;
+    mx = 4 * df * df > mx ? 4 * df * df : mx;
+    c->scratch_h2 = c->cfg.gemm_precision ? a.f(mx) : nullptr;
+  }
+  const bool h2 = c->cfg.gemm_precision != 0;
   c->stem.w = a.f((size_t)c->stem.cout * 64);
   c->stem.bias = a.f(pad32(c->stem.cout));
+  c->stem.h2s = h2 ? a.f(2) : nullptr;
   for (ConvDesc* d : all_convs(c)) {
+    d->h2s = h2 ? a.f(2) : nullptr;
     d->w = a.f(d->w_floats());
     d->bias = d->bn_idx >= 0 ? a.f(d->cout_pad()) : nullptr;
   }
@@ -247,6 +261,10 @@ size_t plan_pack(opp_ctx* c, void* base) {
       e.wmerge = a.f((size_t)d * d);
       e.w1 = a.f((size_t)4 * d * d);
       e.w2 = a.f((size_t)2 * d * d);
+      e.sqkv = h2 ? a.f(2) : nullptr;
+      e.smerge = h2 ? a.f(2) : nullptr;
+      e.s1 = h2 ? a.f(2) : nullptr;
+      e.s2 = h2 ? a.f(2) : nullptr;
       e.g1 = a.f(d);
       e.b1 = a.f(d);
       e.g2 = a.f(d);
@@ -324,6 +342,23 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
   };
   OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
   OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
+  if (c->cfg.gemm_precision) {   // pre-split every GEMM weight matrix into fp16 hi/lo halves (same footprint)
+    auto split = [&](float* wm, size_t n, float* sc) -> int {
+      OPP_TRY(opp_h2_split(wm, c->scratch_h2, n, sc, s));
+      return copy_f(wm, c->scratch_h2, n, s);
+    };
+    OPP_TRY(split(c->stem.w, (size_t)c->stem.cout * 64, c->stem.h2s));
+    for (ConvDesc* d : all_convs(c)) OPP_TRY(split(d->w, d->w_floats(), d->h2s));
+    for (auto* L : {&c->coarse, &c->fine}) {
+      const size_t d = (L == &c->coarse) ? c->cfg.coarse_d_model : c->cfg.fine_d_model;
+      for (auto& e : *L) {
+        OPP_TRY(split(e.wqkv, 3 * d * d, e.sqkv));
+        OPP_TRY(split(e.wmerge, d * d, e.smerge));
+        OPP_TRY(split(e.w1, 4 * d * d, e.s1));
+        OPP_TRY(split(e.w2, 2 * d * d, e.s2));
+      }
+    }
+  }
   c->packed = true;
   c->packed_bytes = need;
   return OPP_OK;
@@ -335,9 +370,11 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
 namespace {
 
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
-             float* y, hipStream_t s, int tile_cfg = -1) {
+             float* y, hipStream_t s, int h2, int tile_cfg = -1) {
   OppGemm g;
   g.conv = 1;
+  g.h2 = h2;
+  g.h2_inv = (h2 && d.h2s) ? d.h2s + 1 : nullptr;
   g.A0 = x;
   g.Bn = 1;
   g.Hin = Hin;
@@ -374,15 +411,15 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
 
 // BasicBlock.forward (resnet.py:37-45)
 int run_block(const float* x, int Hin, int Win, const BlockDesc& b, int stride, float* tmp, float* ds, float* y,
-              hipStream_t s) {
+              hipStream_t s, int h2) {
   const int Ho = Hin / stride, Wo = Win / stride;
-  OPP_TRY(run_conv(x, Hin, Win, b.conv1, stride, nullptr, OPP_RES_NONE, OPP_ACT_RELU, tmp, s));
+  OPP_TRY(run_conv(x, Hin, Win, b.conv1, stride, nullptr, OPP_RES_NONE, OPP_ACT_RELU, tmp, s, h2));
   const float* shortcut = x;
   if (b.has_down) {
-    OPP_TRY(run_conv(x, Hin, Win, b.down, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, ds, s));
+    OPP_TRY(run_conv(x, Hin, Win, b.down, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, ds, s, h2));
     shortcut = ds;
   }
-  return run_conv(tmp, Ho, Wo, b.conv2, 1, shortcut, OPP_RES_DIRECT, OPP_ACT_RELU, y, s);
+  return run_conv(tmp, Ho, Wo, b.conv2, 1, shortcut, OPP_RES_DIRECT, OPP_ACT_RELU, y, s, h2);
 }
 
 struct BackboneBufs {
@@ -423,6 +460,7 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     return OPP_ERR_WORKSPACE;
   }
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  const int hp = c->cfg.gemm_precision ? 1 : 0;
   // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
   OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
   {
@@ -440,22 +478,24 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     g.n_store = pad32(c->stem.cout);
     g.bias = c->stem.bias;
     g.act = OPP_ACT_RELU;
+    g.h2 = hp;
+    g.h2_inv = hp ? c->stem.h2s + 1 : nullptr;
     OPP_TRY(opp_gemm_launch(g, s));
   }
-  OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s));   // layer1 (:144)
-  OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s));
-  OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s));     // layer2 (:145)
-  OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s));
-  OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s));     // layer3 (:146)
-  OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s));
+  OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s, hp));   // layer1 (:144)
+  OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s, hp));
+  OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s, hp));     // layer2 (:145)
+  OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s, hp));
+  OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s, hp));     // layer3 (:146)
+  OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s, hp));
   // FPN (:149-157)
-  OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s));
-  OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s));
-  OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s));
-  OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s));
-  OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s));
-  OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s));
-  OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s));
+  OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
+  OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
+  OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
+  OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
+  OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp));
+  OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
+  OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp));
   return OPP_OK;
 }
 
@@ -537,8 +577,10 @@ size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, T
 }
 
 int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit, const float* W, int M, int N, int K, float* C,
-               int act, hipStream_t s) {
+               int act, hipStream_t s, int h2, const float* h2s) {
   OppGemm g;
+  g.h2 = h2;
+  g.h2_inv = (h2 && h2s) ? h2s + 1 : nullptr;
   g.A0 = A0;
   g.lda0 = lda0;
   g.A1 = A1;
@@ -558,7 +600,7 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
 
 // LocalFeatureTransformer.forward (transformer.py:133-171) on X = [stream0 ; stream1]
 int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cross, int C, int nhead, float* X, int n_seg,
-                     int len0, int len1, Arena& a, hipStream_t s) {
+                     int len0, int len1, Arena& a, hipStream_t s, int h2) {
   const int D = C / nhead;
   const int T0 = n_seg * len0, T1 = n_seg * len1, T = T0 + T1;
   if (T == 0 || layers.empty()) return OPP_OK;
@@ -594,6 +636,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.split_row = T0;
       g.s0 = (float)len0;
       g.s1 = (float)len1;
+      g.h2 = h2;
+      g.h2_inv = (h2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
     }
     const float* q0 = b.qkv;
@@ -608,10 +652,10 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, b.msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps_attn, s));
     OPP_TRY(opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, b.msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps_attn, s));
     }
-    OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s));          // merge (:86)
+    OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s, h2, e.smerge));  // merge (:86)
     OPP_TRY(opp_layernorm(b.mrg, C, e.g1, e.b1, nullptr, 0, b.msg, C, T, C, eps_ln, s));              // norm1 (:87)
-    OPP_TRY(dense_gemm(X, C, b.msg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s));            // mlp.0 on cat([x,msg]) (:91)
-    OPP_TRY(dense_gemm(b.hid, 2 * C, nullptr, 0, 2 * C, e.w2, T, C, 2 * C, b.mrg, OPP_ACT_NONE, s));  // mlp.2
+    OPP_TRY(dense_gemm(X, C, b.msg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s, h2, e.s1));  // mlp.0 on cat([x,msg]) (:91)
+    OPP_TRY(dense_gemm(b.hid, 2 * C, nullptr, 0, 2 * C, e.w2, T, C, 2 * C, b.mrg, OPP_ACT_NONE, s, h2, e.s2));  // mlp.2
     OPP_TRY(opp_layernorm(b.mrg, C, e.g2, e.b2, X, C, X, C, T, C, eps_ln, s));                        // x + norm2 (:92-94)
   }
   return OPP_OK;
@@ -649,8 +693,8 @@ extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg
   OPP_CHECK_ARG(which == 0 || which == 1, "transformer: which must be 0 or 1");
   Arena a(ws, ws_bytes);
   if (which == 0)
-    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream);
-  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream);
+    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, ctx->cfg.gemm_precision ? 1 : 0);
+  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, ctx->cfg.gemm_precision ? 1 : 0);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -766,7 +810,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   a.off = mark;
   OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;
-  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s));
+  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, ctx->cfg.gemm_precision ? 1 : 0));
   a.off = mark;
   return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
                            mkpts_3d, count, a, s);
@@ -799,7 +843,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
   float* f3 = X + (size_t)M * WW * C;
   OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
   if (run_transformer)
-    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s));
+    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, ctx->cfg.gemm_precision ? 1 : 0));
   const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
   return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
 }
@@ -809,7 +853,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
 // ----------------------------------------------------------------------------------------
 extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed, const float* bias,
                                int cout_pad, int ks, int stride, const float* residual, int res_mode, int act, float* y,
-                               int tile_cfg, void* stream) {
+                               int tile_cfg, int h2, const float* h2_scale, void* stream) {
   OPP_CHECK_ARG(x && w_packed && y, "conv2d: null argument");
   OPP_CHECK_ARG(cin_pad % 32 == 0 && cout_pad % 32 == 0, "conv2d: channel counts must be padded to 32");
   ConvDesc d;
@@ -818,7 +862,8 @@ extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, co
   d.ks = ks;
   d.w = const_cast<float*>(w_packed);
   d.bias = const_cast<float*>(bias);
-  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, tile_cfg);
+  d.h2s = const_cast<float*>(h2_scale);
+  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, h2 ? 1 : 0, tile_cfg);
 }
 
 extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
@@ -826,8 +871,16 @@ extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout
   return opp_pack_conv(w, scale, cout, cin, ks, cout_pad, cin_pad, out, (hipStream_t)stream);
 }
 
-extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, void* stream) {
+extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {
+  OPP_CHECK_ARG(in && out, "pack_h2: null argument");
+  return opp_h2_split(in, out, n, scale2, (hipStream_t)stream);
+}
+
+extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, int h2,
+                          const float* h2_scale, void* stream) {
   OppGemm g;
+  g.h2 = h2 ? 1 : 0;
+  g.h2_inv = (h2 && h2_scale) ? h2_scale + 1 : nullptr;
   g.A0 = A;
   g.lda0 = K;
   g.ksplit = K;

@@ -79,6 +79,50 @@ __global__ void stem_im2col_kernel(const float* __restrict__ img, int B, int H, 
   }
 }
 
+// fp16x2 pre-split of a GEMM weight matrix (K-contiguous rows, K % 8 == 0): every 8 consecutive
+// fp32 values become 32 bytes [hi x8 | lo x8], hi = fp16_rtz(x), lo = fp16(x - hi)  (same footprint)
+// sc[0] = 2^(14 - floor(log2(max|w|))) (so that max|w| * sc[0] is in [2^14, 2^15) and every weight
+// above 2^-24 of the largest keeps a normal fp16 lo half), sc[1] = 1 / sc[0]; both exact powers of two
+__global__ __launch_bounds__(1024) void h2_scale_kernel(const float* __restrict__ in, size_t n, float* __restrict__ sc) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = fabsf(in[i]);
+    m = (v < INFINITY && v > m) ? v : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+    int e = 14;
+    if (m > 0.f) e = 14 - ilogbf(m);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    sc[0] = ldexpf(1.f, e);
+    sc[1] = ldexpf(1.f, -e);
+  }
+}
+
+__global__ void h2_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, size_t n8,
+                                const float* __restrict__ sc) {
+  const float mul = sc ? sc[0] : 1.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+    const float v[8] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul, b.x * mul, b.y * mul, b.z * mul, b.w * mul};
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const auto h = __builtin_amdgcn_cvt_pkrtz(v[2 * k], v[2 * k + 1]);
+      const auto l = __builtin_amdgcn_cvt_pkrtz(v[2 * k] - (float)h[0], v[2 * k + 1] - (float)h[1]);
+      hi[k] = __builtin_bit_cast(unsigned, h);
+      lo[k] = __builtin_bit_cast(unsigned, l);
+    }
+    out[2 * i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[2 * i + 1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // out[i] = a[i] + b[i]   (float4 granularity; sizes multiple of 4)
 __global__ void add4_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -135,6 +179,19 @@ int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks), dim3(256), 0, stream, img, B, H, W, Ho, Wo, col);
   OPP_CHECK_LAUNCH("stem_im2col_kernel");
+  return OPP_OK;
+}
+
+int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream_t stream) {
+  OPP_CHECK_ARG(n % 8 == 0 && in != out, "h2_split: n %% 8 != 0 or in-place");
+  const size_t n8 = n / 8;
+  if (scale2) {
+    hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(1024), 0, stream, in, n, scale2);
+    OPP_CHECK_LAUNCH("h2_scale_kernel");
+  }
+  const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(h2_split_kernel, dim3(blocks), dim3(256), 0, stream, in, reinterpret_cast<uint4*>(out), n8, scale2);
+  OPP_CHECK_LAUNCH("h2_split_kernel");
   return OPP_OK;
 }
 

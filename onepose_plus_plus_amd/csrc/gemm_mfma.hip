@@ -32,12 +32,13 @@
 #include "opp_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
 constexpr int kLdsStride = 36;  // floats per LDS tile row: 32 + 4 pad (keeps 16 B alignment)
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, bool H2 = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int TM = BM / WAVES_M / 32;
@@ -199,21 +200,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     for (int i = 0; i < A_LD + B_LD; ++i) load_item(i, a_reg, b_reg);
   };
 
+  // fp16x2 mode (H2): an fp32 value x is carried as hi = fp16_rtz(x), lo = fp16(x - hi) (22 significant
+  // bits).  A 32-k chunk of a row stays 128 B: four groups of 8 k, each [hi x8 | lo x8]; the A operand is
+  // split here, on its way from the prefetch registers to LDS; the weights are pre-split at pack time.
+  auto split_h2 = [](const float4 v, uint2& hi, uint2& lo) {
+    const auto h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const auto h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const auto l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
+    const auto l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
+    hi.x = __builtin_bit_cast(unsigned, h01);
+    hi.y = __builtin_bit_cast(unsigned, h23);
+    lo.x = __builtin_bit_cast(unsigned, l01);
+    lo.y = __builtin_bit_cast(unsigned, l23);
+  };
   auto store_item = [&](int i, int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
-    if (i < A_LD)
-      *reinterpret_cast<float4*>(As + buf * BM * kLdsStride + (lrow + i * (NT / 8)) * kLdsStride + kq * 4) = a_reg[i];
-    else
+    if (i < A_LD) {
+      float* row = As + buf * BM * kLdsStride + (lrow + i * (NT / 8)) * kLdsStride;
+      if (H2) {
+        uint2 hi, lo;
+        split_h2(a_reg[i], hi, lo);
+        float* dst = row + (kq >> 1) * 8 + (kq & 1) * 2;      // group kq/2, elements (kq&1)*4 .. +3
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + 4) = lo;
+      } else {
+        *reinterpret_cast<float4*>(row + kq * 4) = a_reg[i];
+      }
+    } else {
       *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + (lrow + (i - A_LD) * (NT / 8)) * kLdsStride + kq * 4) = b_reg[i - A_LD];
+    }
   };
   auto store_lds = [&](int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
-    float* as = As + buf * BM * kLdsStride;
-    float* bs = Bs + buf * BN * kLdsStride;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i)
-      *reinterpret_cast<float4*>(as + (lrow + i * (NT / 8)) * kLdsStride + kq * 4) = a_reg[i];
-#pragma unroll
-    for (int i = 0; i < B_LD; ++i)
-      *reinterpret_cast<float4*>(bs + (lrow + i * (NT / 8)) * kLdsStride + kq * 4) = b_reg[i];
+    for (int i = 0; i < A_LD + B_LD; ++i) store_item(i, buf, a_reg, b_reg);
   };
 
   f32x16 acc[TM][TN];
@@ -224,13 +242,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int a_frag = (wm * TM * 32 + l31) * kLdsStride + half * 16;
-  const int b_frag = (wn * TN * 32 + l31) * kLdsStride + half * 16;
+  // fp32: lane half h owns k in [16h, 16h+16) of the chunk; fp16x2: it owns k-group 2s+h of k16-step s
+  const int a_frag = (wm * TM * 32 + l31) * kLdsStride + half * (H2 ? 8 : 16);
+  const int b_frag = (wn * TN * 32 + l31) * kLdsStride + half * (H2 ? 8 : 16);
 
   // LDS -> MFMA operand fragments of ONE k-quarter (8 k values: 4 per lane half) of a chunk
+  // (fp16x2: q = 2*step + part, part 0 = the 8 hi halves, 1 = the 8 lo halves of this lane's k-group)
   auto read_frags = [&](int buf, int q, float4 (&af)[TM], float4 (&bf)[TN]) {
-    const float* as = As + buf * BM * kLdsStride + a_frag + q * 4;
-    const float* bs = Bs + buf * BN * kLdsStride + b_frag + q * 4;
+    const int qoff = H2 ? (q >> 1) * 16 + (q & 1) * 4 : q * 4;
+    const float* as = As + buf * BM * kLdsStride + a_frag + qoff;
+    const float* bs = Bs + buf * BN * kLdsStride + b_frag + qoff;
 #pragma unroll
     for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLdsStride);
 #pragma unroll
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   //   read q0 of chunk c+1 | MFMA q3                          -- covers barrier skew + LDS latency
   // so the matrix pipe never waits for a global load, an LDS write or the barrier.
   float4 ga[DEPTH][A_LD], gb[DEPTH][B_LD];   // DEPTH chunks of global prefetch in registers
-  float4 fa[2][TM], fb[2][TN];
+  float4 fa[4][TM], fb[4][TN];   // fp32 uses sets 0,1 ; fp16x2 uses (0,1) = hi/lo of step 0, (2,3) of step 1
   float4 da[A_LD], db[B_LD];   // ablation 5 only: load sink that is never consumed in the loop
 
 #pragma unroll
@@ -288,6 +309,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   store_lds(0, ga[0], gb[0]);
   __syncthreads();
   read_frags(0, 0, fa[0], fb[0]);
+  if (H2) read_frags(0, 1, fa[1], fb[1]);
 
   // The chunk body has no branches: the waitcnt pass can prove that the chunk c+1 registers are
   // the OLDEST loads in flight and waits with a counted vmcnt instead of draining the freshly
@@ -338,12 +360,87 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     mfma_quarter(fa[1], fb[1], nothing);
     __builtin_amdgcn_sched_barrier(0);
   };
+  // ---- fp16x2 variant of the chunk: 2 k16-steps of v_mfma_f32_32x32x16_f16, three products per
+  // tile pair and step (hi*lo + lo*hi + hi*hi, fp32 accumulate): 3/16 of the fp32 MFMA cycles ------
+  auto as_h8 = [](const float4& v) { return *reinterpret_cast<const f16x8*>(&v); };
+  auto mfma_h2 = [&](const float4 (&ah)[TM], const float4 (&al)[TM], const float4 (&bh)[TN], const float4 (&bl)[TN],
+                     bool cross, bool hh, auto&& between) {
+    int n = 0;
+    if (cross) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (tile_ok[j])
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(pr ? al[i] : ah[i]), as_h8(pr ? bh[j] : bl[j]), acc[i][j], 0, 0, 0);
+            between(n);
+            ++n;
+          }
+    }
+    if (hh) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (tile_ok[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(ah[i]), as_h8(bh[j]), acc[i][j], 0, 0, 0);
+          between(n);
+          ++n;
+        }
+    }
+  };
+  constexpr int kSlotsL = 3 * TM * TN;                    // step 0: all three products
+  constexpr int kStrideL = kSlotsL / kItems > 0 ? kSlotsL / kItems : 1;
+  constexpr int kSlotsS = 2 * TM * TN;                    // step 1 cross terms
+  constexpr int kStrideS = kSlotsS / kItems > 0 ? kSlotsS / kItems : 1;
+  auto chunk_h2 = [&](auto set, int lb) {
+    constexpr int P = decltype(set)::value;
+    constexpr int PN = (P + 1) % DEPTH;
+    const int B0 = lb, B1 = lb ^ 1;
+    advance();
+    read_frags(B0, 2, fa[2], fb[2]);
+    read_frags(B0, 3, fa[3], fb[3]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h2(fa[0], fa[1], fb[0], fb[1], true, true, [&](int n) {      // step 0 + prefetch of chunk c+DEPTH
+      if (n % kStrideL == 0 && n / kStrideL < kItems) {
+        load_item(n / kStrideL, ga[P], gb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int i = kSlotsL / kStrideL; i < kItems; ++i) load_item(i, ga[P], gb[P]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h2(fa[2], fa[3], fb[2], fb[3], true, false, [&](int n) {     // step 1 cross terms + LDS hand-over
+      if (n % kStrideS == 0 && n / kStrideS < kItems) {
+        store_item(n / kStrideS, B1, ga[PN], gb[PN]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int i = kSlotsS / kStrideS; i < kItems; ++i) store_item(i, B1, ga[PN], gb[PN]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(B1, 0, fa[0], fb[0]);
+    read_frags(B1, 1, fa[1], fb[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_h2(fa[2], fa[3], fb[2], fb[3], false, true, nothing);        // step 1 hi*hi covers barrier + LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
   for (int c = 0; c < nk; c += DEPTH) {
-    chunk(std::integral_constant<int, 0>{}, c & 1);
-    if (DEPTH > 1) chunk(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
-    if (DEPTH > 2) chunk(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
-    if (DEPTH > 3) chunk(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
+    if (H2) {
+      chunk_h2(std::integral_constant<int, 0>{}, c & 1);
+      if (DEPTH > 1) chunk_h2(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+      if (DEPTH > 2) chunk_h2(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
+      if (DEPTH > 3) chunk_h2(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
+    } else {
+      chunk(std::integral_constant<int, 0>{}, c & 1);
+      if (DEPTH > 1) chunk(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+      if (DEPTH > 2) chunk(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
+      if (DEPTH > 3) chunk(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
+    }
   }
   if (ABL == 5) {
 #pragma unroll
@@ -357,7 +454,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // lane per store).  Stage the tile through the (now idle) LDS operand buffers and write it
   // out row-contiguously with 16 B per lane: full 128 B lines for the stores, the residual and
   // the bias, and the per-row work (bilinear taps, value scaling) is done once per 4 outputs.
-  constexpr int JP = TN < 4 ? TN : 4;                      // n-subtiles per wave staged per pass
+  constexpr int kJPmax = TN < 4 ? TN : 4;
+  constexpr int kOperandFloats = 2 * (BM + BN) * kLdsStride;
+  // n-subtiles per wave staged per pass: as many as fit the operand buffers
+  constexpr int JP = (BM * (WAVES_N * kJPmax * 32 + 4) <= kOperandFloats) ? kJPmax
+                     : (BM * (WAVES_N * 2 * 32 + 4) <= kOperandFloats && kJPmax >= 2) ? 2 : 1;
   constexpr int NPASS = (TN + JP - 1) / JP;
   constexpr int WP = WAVES_N * JP * 32;                    // staged columns per pass
   constexpr int CS = WP + 4;                               // LDS row stride (floats)
@@ -365,6 +466,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   float* Cs = smem;
   const bool scale_on = (g.out_mul != 1.f) || (g.out_div != 1.f);
   const bool vec_ok = g.vec_epilogue != 0;
+  // fp16x2: the weight matrix was pre-scaled by a power of two (its fp16 lo halves stay normal); undo, exactly
+  const float h2_inv = (H2 && g.h2_inv != nullptr) ? *g.h2_inv : 1.f;
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();   // operand buffers (or the previous pass) are no longer read
@@ -377,7 +480,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int lr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float cv0 = acc[i][j][r];
+            const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
             Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
           }
         }
@@ -531,12 +634,44 @@ int launch_ablate(const OppGemm& g, hipStream_t stream) {   // tuning only: 128x
   return OPP_OK;
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH>
+int launch_cfg_h2(const OppGemm& g, hipStream_t stream) {   // fp16x2-split operands (weights pre-split)
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  if constexpr (BN == 128 || BN == 64 || BN == 256) {
+    const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float);
+    const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
+    if (g.conv) {
+      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, true>;
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+    } else {
+      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH, true>;
+      static bool attr_done = false;
+      if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+    }
+    OPP_CHECK_LAUNCH("opp_gemm_kernel(fp16x2)");
+    return OPP_OK;
+  } else {
+    opp_set_error("gemm: the fp16x2 variant is built for the 128/64-column tiles only");
+    return OPP_ERR_UNSUPPORTED;
+  }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH = 2>
 int launch_cfg(const OppGemm& g, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   static const size_t extra_lds = getenv("OPP_EXTRA_LDS") ? (size_t)atoi(getenv("OPP_EXTRA_LDS")) : 0;  // tuning knob
   const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float) + extra_lds;
   const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
+  if (g.h2) return launch_cfg_h2<BM, BN, WAVES_M, WAVES_N, DEPTH>(g, stream);
   if (g.conv) {
     auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH>;
     static bool attr_done = false;
@@ -603,7 +738,8 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     else cfg = 2;
     // prefetch depth of the long-K convolutions on 128x128 tiles: 4 register sets when the grid
     // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
-    if (g.conv && g.K >= 768 && cfg == 0) cfg = t0 <= 512 ? 11 : 10;
+    // (fp16x2: the MFMA phase is 5x shorter, depth 2 measured best on every layer)
+    if (g.conv && g.K >= 768 && cfg == 0 && !g.h2) cfg = t0 <= 512 ? 11 : 10;
   }
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
@@ -629,6 +765,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 5: rc = launch_cfg<64, 224, 2, 2>(g, stream); break;   // 4 waves: N split 128 + 96
     case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // prefetch depth experiments
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
+    case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
+    case 21: rc = launch_cfg<256, 128, 4, 2, 3>(g, stream); break;
+    case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
     case 101: rc = g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID; break;
     case 102: rc = g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID; break;
     case 103: rc = g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID; break;

@@ -81,6 +81,10 @@ struct OppGemm {
   float out_mul = 1.f, out_div = 1.f;
   // operand extents in bytes for the buffer descriptors (filled by the launcher)
   unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;
+  // 1 = fp16x2-split operands: W is pre-split ([hi x8 | lo x8] per 8 k), A is split on the fly;
+  // three v_mfma_f32_32x32x16_f16 products per k16-step, fp32 accumulate (22-bit operand mantissas)
+  int h2 = 0;
+  const float* h2_inv = nullptr;   // device scalar: 1 / (power-of-two scale applied to W before the split), or null
   int xcd_swizzle = 1;
   int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
   // optional softmax statistics of the OUTPUT tile (score GEMM of the coarse matcher): per row

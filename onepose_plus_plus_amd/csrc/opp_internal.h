@@ -22,6 +22,8 @@ int opp_pack_conv(const float* w, const float* scale, int cout, int cin, int ks,
                   float* out, hipStream_t stream);
 int opp_pack_stem(const float* w, const float* scale, int cout, float* out, hipStream_t stream);
 int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream_t stream);
+// fp16x2 pre-split; scale2 (device, 2 floats: scale, 1/scale) null = unscaled
+int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream_t stream);
 int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
 int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream);
 // kpt.hip

@@ -15,6 +15,7 @@ PyTorch is only used for parameter storage, device memory and the current stream
 NO CPU / PyTorch fallback: CPU tensors, training mode, or a missing library raise.
 """
 import ctypes
+import os
 import math
 import warnings
 
@@ -137,6 +138,10 @@ def _validate_config(cfg):
         raise NotImplementedError()
 
 
+GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1}
+DEFAULT_GEMM_PRECISION = "fp32"
+
+
 class OnePosePlus_model(nn.Module):
     def __init__(self, config, profiler=None, debug=False):
         super().__init__()
@@ -165,7 +170,20 @@ class OnePosePlus_model(nn.Module):
             if config["loftr_backbone"]["pretrained_fix"]:
                 for p in self.backbone.parameters():
                     p.requires_grad = False
+        self.gemm_precision = os.environ.get("OPP_GEMM_PRECISION", DEFAULT_GEMM_PRECISION)
         self._reset_runtime()
+
+    def set_gemm_precision(self, name):
+        """Arithmetic of the conv / Linear GEMMs: "fp32" (fp32 MFMA) or "fp16x2" (hi/lo fp16 split,
+        three fp16 MFMAs per product, fp32 accumulate; see include/opp_hip.h opp_config.gemm_precision).
+        Not a reference option; both satisfy the 1e-4 parity bar (tests/test_e2e_gpu.py)."""
+        if name not in GEMM_PRECISIONS:
+            raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
+        if name != self.gemm_precision:
+            self.__del__()
+            self.gemm_precision = name
+            self._reset_runtime()
+        return self
 
     # ---- runtime state (never pickled) ---------------------------------------------------
     def _reset_runtime(self):
@@ -239,6 +257,9 @@ class OnePosePlus_model(nn.Module):
         c.match_thr = float(cm["thr"])
         c.match_border_rm = int(cm["border_rm"])
         c.match_temperature = float(cm["dual_softmax"]["temperature"])
+        if self.gemm_precision not in GEMM_PRECISIONS:
+            raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
+        c.gemm_precision = GEMM_PRECISIONS[self.gemm_precision]
         return c
 
     def _ensure_ready(self, device):

@@ -14,14 +14,28 @@ def pad32(c):
     return (c + 31) // 32 * 32
 
 
-def linear(A, W, act=0, cfg=-1):
+def pack_h2(w, scaled=True):
+    """-> (pre-split weights, device {scale, 1/scale} or None)"""
+    lib = _lib.load()
+    out = torch.empty_like(w)
+    sc = torch.zeros(2, device="cuda") if scaled else None
+    _lib.check(lib.opp_pack_h2(w.data_ptr(), out.data_ptr(), w.numel(), sc.data_ptr() if scaled else None, _s()),
+               "opp_pack_h2")
+    return out, sc
+
+
+def linear(A, W, act=0, cfg=-1, h2=0):
     lib = _lib.load()
     A = A.cuda().contiguous()
     W = W.cuda().contiguous()
     M, K = A.shape
     N = W.shape[0]
+    sc = None
+    if h2:
+        W, sc = pack_h2(W, scaled=(h2 == 1))
     C = torch.full((M, N), float("nan"), device="cuda")
-    _lib.check(lib.opp_linear(A.data_ptr(), M, K, W.data_ptr(), N, act, C.data_ptr(), cfg, _s()), "opp_linear")
+    _lib.check(lib.opp_linear(A.data_ptr(), M, K, W.data_ptr(), N, act, C.data_ptr(), cfg, 1 if h2 else 0,
+                              sc.data_ptr() if sc is not None else None, _s()), "opp_linear")
     torch.cuda.synchronize()
     return C.cpu()
 
@@ -38,7 +52,7 @@ def from_nhwc(y, c):
     return y[:, :, :c].permute(2, 0, 1).unsqueeze(0).cpu()
 
 
-def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0, act=0, cfg=-1):
+def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0, act=0, cfg=-1, h2=0):
     """x [1,Cin,H,W]; w [Cout,Cin,k,k]; y = act(conv(x, w*scale) + bias + residual)."""
     lib = _lib.load()
     cout, cin, ks, _ = w.shape
@@ -55,6 +69,9 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
         sd[:cout] = scale.cuda()
     _lib.check(lib.opp_pack_conv_weight(wd.data_ptr(), sd.data_ptr() if sd is not None else None, cout, cin, ks,
                                         cout_p, cin_p, wp.data_ptr(), _s()), "pack")
+    sc = None
+    if h2:
+        wp, sc = pack_h2(wp, scaled=(h2 == 1))
     bd = None
     if bias is not None:
         bd = torch.zeros(cout_p, device="cuda")
@@ -65,7 +82,8 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
     y = torch.full((Ho, Wo, cout_p), float("nan"), device="cuda")
     _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin_p, wp.data_ptr(), bd.data_ptr() if bd is not None else None,
                                    cout_p, ks, stride, rd.data_ptr() if rd is not None else None, res_mode, act,
-                                   y.data_ptr(), cfg, _s()), "conv2d")
+                                   y.data_ptr(), cfg, 1 if h2 else 0, sc.data_ptr() if sc is not None else None, _s()),
+               "conv2d")
     torch.cuda.synchronize()
     pad_part = y[:, :, cout:]
     return from_nhwc(y, cout), (pad_part.abs().max().item() if pad_part.numel() else 0.0)
@@ -83,9 +101,14 @@ def layer_norm(x, g, b, res=None):
     return out.cpu()
 
 
-def make_model(cfg, sd):
+PRECISIONS = ("fp32", "fp16x2")
+
+
+def make_model(cfg, sd, precision=None):
     m = OnePosePlus_model(cfg).eval()
     m.load_state_dict(sd, strict=True)
+    if precision is not None:
+        m.set_gemm_precision(precision)
     return m.cuda()
 
 

@@ -11,11 +11,15 @@ from tests.golden.cases import E2E_CASES
 pytestmark = pytest.mark.gpu
 
 
+PRECISIONS = ["fp32", "fp16x2"]     # both GEMM arithmetics meet the same parity bar
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", list(E2E_CASES))
-def test_e2e_vs_golden(name):
+def test_e2e_vs_golden(name, precision):
     from tests import hip_ops as ops
     cfg, sd, data = H.e2e_setup(name)
-    model = ops.make_model(cfg, sd)
+    model = ops.make_model(cfg, sd, precision)
     out = ops.run_model(model, data)
     gold = H.load_golden(name)
     H.assert_match_outputs(out, gold, where=name)
@@ -32,11 +36,12 @@ def test_e2e_vs_golden(name):
     assert out["mkpts_query_f"].shape == (len(gold["mconf"]), 2)
 
 
-def test_e2e_vs_oracle_and_determinism():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_e2e_vs_oracle_and_determinism(precision):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
     cfg, sd, data = H.e2e_setup("e2e_128x128_n300_thr0")
-    model = ops.make_model(cfg, sd)
+    model = ops.make_model(cfg, sd, precision)
     out1 = ops.run_model(model, data)
     out2 = ops.run_model(model, data)
     for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
@@ -52,14 +57,14 @@ def test_e2e_vs_oracle_and_determinism():
         assert torch.equal(v, data[k]), k
 
 
-@pytest.mark.parametrize("n", [5000, 15000])
-def test_full_size_properties(n):
+@pytest.mark.parametrize("n,precision", [(5000, "fp32"), (5000, "fp16x2"), (15000, "fp32"), (15000, "fp16x2")])
+def test_full_size_properties(n, precision):
     """BASELINE sizes: properties that hold for any input (no oracle needed)."""
     from tests import hip_ops as ops
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
     from onepose_plus_plus_amd.config import default_config
     cfg = default_config(thr=0.0)
-    model = ops.make_model(cfg, make_state_dict(cfg, 0))
+    model = ops.make_model(cfg, make_state_dict(cfg, 0), precision)
     out = ops.run_model(model, make_inputs(n, (512, 512), 1))
     conf = out["conf_matrix"][0]
     assert torch.isfinite(conf).all() and (conf >= 0).all()
@@ -134,3 +139,20 @@ def test_matcher_pool_matches_sequential():
     for r, g in zip(ref, got):
         for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
             assert torch.equal(r[k], g[k]), k
+
+
+def test_precisions_agree_at_full_size():
+    """512x512 x 5k points, thr 0: the fp16x2-split GEMMs select exactly the matches of the fp32 GEMMs and
+    agree on confidences / fine offsets far inside the 1e-4 bar."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    from onepose_plus_plus_amd.config import default_config
+    cfg = default_config(thr=0.0)
+    sd = make_state_dict(cfg, 0)
+    outs = [ops.run_model(ops.make_model(cfg, sd, p), make_inputs(5000, (512, 512), 1)) for p in PRECISIONS]
+    a, b = outs
+    assert len(a["i_ids"]) > 0
+    assert torch.equal(a["i_ids"], b["i_ids"]) and torch.equal(a["j_ids"], b["j_ids"])
+    assert (a["conf_matrix"] - b["conf_matrix"]).abs().max() < 2e-5
+    assert (a["mconf"] - b["mconf"]).abs().max() < 2e-5
+    assert (a["expec_f"] - b["expec_f"]).abs().max() < 1e-4

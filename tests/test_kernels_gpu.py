@@ -26,6 +26,39 @@ def test_linear_tiles(M, K, N, cfg):
     assert (err <= 2e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (77, 256, 96), (50, 64, 81),
+                                   (33, 96, 7), (515, 1152, 130)])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 10, 11])
+def test_linear_fp16x2(M, K, N, cfg):
+    """fp16x2-split operands (hi + lo fp16, three fp16 MFMAs, fp32 accumulate): same error class as fp32."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    ref = (A.double() @ W.double().T).float()
+    got = ops.linear(A, W, 0, cfg, h2=1)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert (err <= 2e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
+
+
+@pytest.mark.parametrize("sa,sw", [(1.0, 0.02), (1.0, 1e-4), (1.0, 300.0), (30.0, 1e-6), (0.05, 0.02)])
+def test_linear_fp16x2_weight_magnitudes(sa, sw):
+    """The per-matrix power-of-two weight scale keeps the fp16 lo halves normal: accuracy does not depend on
+    the weight magnitude; the un-scaled split (h2=2) degrades for small weights (fp16 subnormal lo)."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(256, 1152, generator=g) * sa
+    W = torch.randn(192, 1152, generator=g) * sw
+    ref = A.double() @ W.double().T
+    bound = A.abs().double() @ W.abs().double().T
+    e_scaled = ((ops.linear(A, W, 0, -1, h2=1).double() - ref).abs() / bound).max().item()
+    assert e_scaled < 1e-6, e_scaled
+    if sw <= 1e-4:
+        e_raw = ((ops.linear(A, W, 0, -1, h2=2).double() - ref).abs() / bound).max().item()
+        assert e_raw > 4 * e_scaled, (e_raw, e_scaled)
+
+
 @pytest.mark.parametrize("cfg", [3, 5, 10, 11, -1])
 @pytest.mark.parametrize("N", [224, 448])
 def test_linear_224_tiles(cfg, N):
@@ -78,6 +111,27 @@ def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
     assert pad_max == 0.0          # padded channels must stay exactly zero
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+def test_conv_fp16x2(cin, cout, ks, stride, H, W, cfg):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+    res = torch.randn(1, cout, Ho, Wo, generator=g)
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride, ks // 2) + res.double()
+    ref = F.relu(ref).float()
+    got, pad_max = ops.conv2d(x, w, scale, bias, stride, res, 1, 1, cfg, h2=1)
+    assert pad_max == 0.0
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(Exception):          # the 224-column tiles have no fp16x2 build: refused, not silently fp32
+        ops.conv2d(x, w, scale, bias, stride, res, 1, 1, 3, h2=1)
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(196, 256, 12, 16), (128, 196, 20, 12)])

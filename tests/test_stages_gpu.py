@@ -14,12 +14,12 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
 
 
-@pytest.fixture(scope="module")
-def small():
+@pytest.fixture(scope="module", params=["fp32", "fp16x2"])
+def small(request):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
     cfg, sd, data = H.e2e_setup("e2e_128x128_n300_thr0")
-    model = ops.make_model(cfg, sd)
+    model = ops.make_model(cfg, sd, request.param)
     with torch.no_grad():
         st = O.backbone_forward(sd, data["query_image"], stages=True)
     return cfg, sd, data, model, st
