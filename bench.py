@@ -33,8 +33,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-DOMINANT_CFG, DOMINANT_CONV = 11, 1
-DOMINANT_NAME = "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)"
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (32x32x16)
+# dominant kernel per GEMM precision: (tile cfg, conv, name, peak in ALGORITHMIC TFLOP/s)
+DOMINANT = {
+    "fp32": (11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", PEAK_F32_MFMA_TFLOPS),
+    # three fp16 MFMA products per algorithmic multiply-add -> a third of the fp16 dense peak
+    "fp16x2": (20, 1, "opp_gemm_kernel<256,128,4,2,conv,depth2,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv)",
+               PEAK_F16_MFMA_TFLOPS / 3.0),
+}
 
 
 def main():
@@ -48,6 +54,8 @@ def main():
     ap.add_argument("--thr", type=float, default=0.1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp16x2"],
+                    help="GEMM arithmetic (default: the module default / OPP_GEMM_PRECISION)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "2")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
                          "2 Ray workers per GPU, inference_OnePosePlus.py:18-26); steps are split evenly")
@@ -75,6 +83,10 @@ def main():
 
     cfg = default_config(thr=args.thr, fine=args.fine)
     model = OnePosePlus_model(cfg).eval()
+    if args.precision:
+        model.set_gemm_precision(args.precision)
+    precision = model.gemm_precision
+    DOMINANT_CFG, DOMINANT_CONV, DOMINANT_NAME, PEAK = DOMINANT[precision]
     sd = make_state_dict(cfg, 0) if rank == 0 else None
     model = model.to(dev)
     if dist is not None:
@@ -87,7 +99,7 @@ def main():
         raise SystemExit("--steps must be a multiple of --streams")
     models = [model]
     for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
-        m = OnePosePlus_model(cfg).eval().to(dev)
+        m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).to(dev)
         m.load_state_dict(model.state_dict(), strict=True)
         models.append(m)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
@@ -170,13 +182,13 @@ def main():
         _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
         if n.value > 0 and ms.value > 0:
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel.json")
+            tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel%s.json" % ("" if precision == "fp32" else "_" + precision))
             if os.path.exists(tpath):     # HBM bytes per launch from the committed rocprofv3 --pmc passes
                 with open(tpath) as f:
                     traffic = json.load(f)
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": DOMINANT_NAME,
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK, 4), "traffic": traffic, "kernel": DOMINANT_NAME,
                     "measured": "HIP events on the launch stream, " + ("timed region" if prof_in_timed else
                                 "single-stream pass of the same steps after the timed region"),
                     "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
@@ -197,12 +209,13 @@ def main():
             "metric": "query images/sec (2D-3D match fwd) at 512x512 img x 5k pts",
             "value": round(total / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if precision == "fp32" else "f32 (GEMM operands as hi+lo fp16 pairs, fp32 accumulate)",
             "data": "synthetic (seeded random image, descriptor bank and weights)",
             "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
                                    "%d forward(s) in flight per GPU, one object per GPU"
                                    % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams),
-                       "streams_per_gpu": n_streams,
+                       "streams_per_gpu": n_streams, "gemm_precision": precision,
                        "matches_last_step": int(last["mconf"].numel()),
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),

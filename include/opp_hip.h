@@ -171,6 +171,10 @@ int opp_pnp_ransac(const float* pts2d, const float* pts3d, int n_points, const d
                    int refine_iters, double* pose_out, int* inlier_mask, int* n_inliers, int* ok,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Tuning aid: device buffer (4 x uint64 per wave) for the phase time stamps written by the timed conv
+ * variants (tile_cfg 120 = 256x128 / 8 waves, 121 = 128x128 / 4 waves); NULL disables. */
+int opp_debug_timestamps(void* buf);
+
 /* ---- live kernel timing for bench.py's roofline leg ---------------------------------------
  * Arms HIP-event timing (events recorded on the launch stream) of every launch of one GEMM /
  * implicit-conv kernel symbol: tile_cfg 0..4 (128x128, 64x128, 64x64, 128x224, 64x224), conv 1/0.

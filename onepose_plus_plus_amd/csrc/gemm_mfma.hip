@@ -50,6 +50,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "load split");
 
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (ABL == 9 || ABL > 90) ts0 = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                         // [2][BM][36]
   float* Bs = smem + 2 * BM * kLdsStride;   // [2][BN][36]
@@ -88,12 +90,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // byte offset beyond num_records: the buffer unit returns zeros, so there is no exec-masked
   // control flow in the K loop and the loads can be scheduled among the MFMAs.
   constexpr unsigned kOob = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, g.a0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A1 ? g.A1 : g.A0), 0, g.A1 ? g.a1_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, g.w_bytes, 0x00020000);
 
   // byte offset of each load slot's row start (+ this thread's float4); kOob for rows >= M.
-  // conv mode: a_mask bit t = tap t of the window falls inside the image for this output pixel.
+  // conv mode: a_mask bit t = tap t of the window falls OUTSIDE the image for this output pixel.
   unsigned a_base0[A_LD], a_base1[A_LD], a_mask[A_LD];
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
@@ -116,7 +115,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
                           (unsigned)(ix0 + kx) < (unsigned)g.Win;
           m |= (ok ? 1u : 0u) << (ky * g.ksize + kx);
         }
-      a_mask[i] = r < g.M ? m : 0u;
+      a_mask[i] = r < g.M ? ~m : 0xffffffffu;   // bit t set = tap t must read zeros
     } else {
       a_base0[i] = r < g.M ? (unsigned)(r * g.lda0 + kq * 4) * 4u : kOob;
       a_base1[i] = r < g.M ? (unsigned)(r * g.lda1 + kq * 4) * 4u : kOob;
@@ -179,20 +178,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   auto load_item = [&](int i, float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
     if (ABL == 6 && i >= A_LD) return;   // ablation: no weight loads
     if (ABL == 7 && i < A_LD) return;    // ablation: no activation loads
-    const unsigned past = cur_past;
+    // chunks past the end of K: a zero-sized buffer (one s_cselect on the wave-uniform descriptor)
+    const bool live = cur_past == 0u;
     if (i < A_LD) {
       if (CONV) {
-        // pure data flow (no exec masking): invalid tap -> bit 31 set -> out of range -> zeros
-        const unsigned bad = (((a_mask[i] >> cur_tap) & 1u) - 1u) & kOob;
-        a_reg[i] = bload(rsrc_a0, (a_base0[i] + cur_delta) | past | bad);
+        // pure data flow (no exec masking): a_mask holds the INVALID taps, so shifting the current
+        // tap's bit to bit 31 yields the out-of-range offset directly (shift, add, and-or per load)
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, live ? g.a0_bytes : 0, 0x00020000);
+        const unsigned bad = a_mask[i] << (31 - cur_tap);
+        a_reg[i] = bload(r, (bad & kOob) | (a_base0[i] + cur_delta));
       } else if (cur_k0 < g.ksplit) {
         // (kOob + small) stays out of range, so invalid rows need no select
-        a_reg[i] = bload(rsrc_a0, (a_base0[i] + (unsigned)cur_k0 * 4u) | past);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, live ? g.a0_bytes : 0, 0x00020000);
+        a_reg[i] = bload(r, a_base0[i] + (unsigned)cur_k0 * 4u);
       } else {
-        a_reg[i] = bload(rsrc_a1, (a_base1[i] + (unsigned)(cur_k0 - g.ksplit) * 4u) | past);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A1 ? g.A1 : g.A0), 0, (live && g.A1) ? g.a1_bytes : 0, 0x00020000);
+        a_reg[i] = bload(r, a_base1[i] + (unsigned)(cur_k0 - g.ksplit) * 4u);
       }
     } else {
-      b_reg[i - A_LD] = bload(rsrc_w, (b_base[i - A_LD] + (unsigned)cur_k0 * 4u) | past);
+      const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, live ? g.w_bytes : 0, 0x00020000);
+      b_reg[i - A_LD] = bload(r, b_base[i - A_LD] + (unsigned)cur_k0 * 4u);
     }
   };
   auto load_global = [&](float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
@@ -203,15 +208,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // fp16x2 mode (H2): an fp32 value x is carried as hi = fp16_rtz(x), lo = fp16(x - hi) (22 significant
   // bits).  A 32-k chunk of a row stays 128 B: four groups of 8 k, each [hi x8 | lo x8]; the A operand is
   // split here, on its way from the prefetch registers to LDS; the weights are pre-split at pack time.
+  // hi = fp16_rtz(x) (one v_cvt_pkrtz per pair); lo = fp16_rne(x - hi) straight from the packed hi with
+  // v_fma_mix{lo,hi}_f16 (f16 source * -1 + f32 source, rounded once to f16): 6 VALU per float4, not 14
   auto split_h2 = [](const float4 v, uint2& hi, uint2& lo) {
-    const auto h01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
-    const auto h23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-    const auto l01 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h01[0], v.y - (float)h01[1]);
-    const auto l23 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h23[0], v.w - (float)h23[1]);
-    hi.x = __builtin_bit_cast(unsigned, h01);
-    hi.y = __builtin_bit_cast(unsigned, h23);
-    lo.x = __builtin_bit_cast(unsigned, l01);
-    lo.y = __builtin_bit_cast(unsigned, l23);
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    unsigned l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(v.x));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(v.y));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(v.z));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(v.w));
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(l01, l23);
   };
   auto store_item = [&](int i, int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
     if (i < A_LD) {
@@ -404,23 +412,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     __builtin_amdgcn_sched_barrier(0);
     mfma_h2(fa[0], fa[1], fb[0], fb[1], true, true, [&](int n) {      // step 0 + prefetch of chunk c+DEPTH
       if (n % kStrideL == 0 && n / kStrideL < kItems) {
-        load_item(n / kStrideL, ga[P], gb[P]);
+        if (ABL != 91) load_item(n / kStrideL, ga[P], gb[P]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
-    for (int i = kSlotsL / kStrideL; i < kItems; ++i) load_item(i, ga[P], gb[P]);
+    for (int i = kSlotsL / kStrideL; i < kItems; ++i)
+      if (ABL != 91) load_item(i, ga[P], gb[P]);
     __builtin_amdgcn_sched_barrier(0);
     mfma_h2(fa[2], fa[3], fb[2], fb[3], true, false, [&](int n) {     // step 1 cross terms + LDS hand-over
       if (n % kStrideS == 0 && n / kStrideS < kItems) {
-        store_item(n / kStrideS, B1, ga[PN], gb[PN]);
+        if (ABL != 92) store_item(n / kStrideS, B1, ga[PN], gb[PN]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
-    for (int i = kSlotsS / kStrideS; i < kItems; ++i) store_item(i, B1, ga[PN], gb[PN]);
+    for (int i = kSlotsS / kStrideS; i < kItems; ++i)
+      if (ABL != 92) store_item(i, B1, ga[PN], gb[PN]);
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
+    if (ABL != 93) __syncthreads();
     read_frags(B1, 0, fa[0], fb[0]);
     read_frags(B1, 1, fa[1], fb[1]);
     __builtin_amdgcn_sched_barrier(0);
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  if (ABL == 9 || ABL > 90) ts1 = __builtin_readcyclecounter();
   // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
   for (int c = 0; c < nk; c += DEPTH) {
     if (H2) {
@@ -442,6 +453,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       if (DEPTH > 3) chunk(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
     }
   }
+  if (ABL == 9 || ABL > 90) ts2 = __builtin_readcyclecounter();
   if (ABL == 5) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) asm volatile("" ::"v"(da[i].x), "v"(da[i].w));
@@ -486,34 +498,109 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         }
       }
     __syncthreads();
-    if (g.stat_rowmax != nullptr && NPASS == 1 && !kRagged) {
-      // fused dual-softmax statistics (coarse_matching.py:115): partial (max, sum exp) of this
-      // tile per row (over its columns) and per column (over its rows); merged by tiny kernels
-      const int tiles_m_all = (g.M + BM - 1) / BM;
-      (void)tiles_m_all;
-      const int ncols = min(WP, g.n_store - n0);
-      const int nrows = min(BM, g.M - m0);
-      for (int lr = wave; lr < nrows; lr += WAVES_M * WAVES_N) {
-        float mx = -INFINITY;
-        for (int c = lane; c < ncols; c += 64) mx = fmaxf(mx, Cs[lr * CS + c]);
+    if constexpr (NPASS == 1 && !kRagged && (NT % BM) == 0 && kOperandFloats - BM * CS >= 2 * (NT / BM) * BM + 2 * WAVES_M * WP) {
+      if (g.stat_rowmax != nullptr) {
+        // fused dual-softmax statistics (coarse_matching.py:115): partial (max, sum exp) of this tile per
+        // row (over its columns) and per column (over its rows); merged by tiny kernels.  Every partial is a
+        // fixed-order function of the row's / column's values only, so duplicated rows or columns get
+        // bit-equal statistics wherever they sit (exact ties then resolve like the reference's).
+        constexpr int kParts = NT / BM;                 // threads per row
+        constexpr int kQ = WP / 4 / kParts;             // float4 per thread
+        float* sc_r = Cs + BM * CS;                     // [kParts][BM] scratch behind the staged tile
+        float* sc_c = sc_r + 2 * kParts * BM;           // [WAVES_M][WP]
+        const int ncols = min(WP, g.n_store - n0);
+        const int nrows = min(BM, g.M - m0);
+        {  // rows: thread = (row, part); 16 lanes of a ds_read_b128 group read 16 rows -> conflict-free (CS = 4 mod 64)
+          const int lr = tid % BM, part = tid / BM;
+          const float* rowp = Cs + lr * CS + part * kQ * 4;
+          float mx = -INFINITY;
+#pragma unroll 4
+          for (int q = 0; q < kQ; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(rowp + q * 4);
+            const int c = (part * kQ + q) * 4;
+            mx = fmaxf(mx, c + 0 < ncols ? v.x : -INFINITY);
+            mx = fmaxf(mx, c + 1 < ncols ? v.y : -INFINITY);
+            mx = fmaxf(mx, c + 2 < ncols ? v.z : -INFINITY);
+            mx = fmaxf(mx, c + 3 < ncols ? v.w : -INFINITY);
+          }
+          sc_r[part * BM + lr] = mx;
+          __syncthreads();
+          mx = sc_r[lr];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sm = 0.f;
-        for (int c = lane; c < ncols; c += 64) sm += expf(Cs[lr * CS + c] - mx);
+          for (int pp = 1; pp < kParts; ++pp) mx = fmaxf(mx, sc_r[pp * BM + lr]);
+          float sm = 0.f;
+#pragma unroll 4
+          for (int q = 0; q < kQ; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(rowp + q * 4);
+            const int c = (part * kQ + q) * 4;
+            sm += c + 0 < ncols ? __expf(v.x - mx) : 0.f;
+            sm += c + 1 < ncols ? __expf(v.y - mx) : 0.f;
+            sm += c + 2 < ncols ? __expf(v.z - mx) : 0.f;
+            sm += c + 3 < ncols ? __expf(v.w - mx) : 0.f;
+          }
+          sc_r[(kParts + part) * BM + lr] = sm;
+          __syncthreads();
+          if (part == 0 && lr < nrows) {
+            float tot = sc_r[kParts * BM + lr];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
-        if (lane == 0) {
-          g.stat_rowmax[(size_t)(m0 + lr) * tiles_n + tile_n] = mx;
-          g.stat_rowsum[(size_t)(m0 + lr) * tiles_n + tile_n] = sm;
+            for (int pp = 1; pp < kParts; ++pp) tot += sc_r[(kParts + pp) * BM + lr];
+            g.stat_rowmax[(size_t)(m0 + lr) * tiles_n + tile_n] = mx;
+            g.stat_rowsum[(size_t)(m0 + lr) * tiles_n + tile_n] = tot;
+          }
         }
-      }
-      for (int c = tid; c < ncols; c += NT) {
-        float mx = -INFINITY;
-        for (int lr = 0; lr < nrows; ++lr) mx = fmaxf(mx, Cs[lr * CS + c]);
-        float sm = 0.f;
-        for (int lr = 0; lr < nrows; ++lr) sm += expf(Cs[lr * CS + c] - mx);
-        g.stat_colmax[(size_t)tile_m * g.n_store + n0 + c] = mx;
-        g.stat_colsum[(size_t)tile_m * g.n_store + n0 + c] = sm;
+        {  // columns: straight from the accumulators (lane = column), same scaled value as stored
+          auto sval = [&](int i, int j, int r) -> float {
+            const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
+            return scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
+          };
+          auto rvalid = [&](int i, int r) -> bool {
+            return wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < nrows;
+          };
+          float cmx[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) m = fmaxf(m, rvalid(i, r) ? sval(i, j, r) : -INFINITY);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            if (half == 0) sc_c[wm * WP + wn * TN * 32 + j * 32 + l31] = m;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float m = sc_c[wn * TN * 32 + j * 32 + l31];
+#pragma unroll
+            for (int w = 1; w < WAVES_M; ++w) m = fmaxf(m, sc_c[w * WP + wn * TN * 32 + j * 32 + l31]);
+            cmx[j] = m;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sm += rvalid(i, r) ? __expf(sval(i, j, r) - cmx[j]) : 0.f;
+            sm += __shfl_xor(sm, 32, 64);
+            if (half == 0) sc_c[wm * WP + wn * TN * 32 + j * 32 + l31] = sm;
+          }
+          __syncthreads();
+          if (wm == 0 && half == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int c = wn * TN * 32 + j * 32 + l31;
+              if (c < ncols) {
+                float tot = sc_c[c];
+#pragma unroll
+                for (int w = 1; w < WAVES_M; ++w) tot += sc_c[w * WP + c];
+                g.stat_colmax[(size_t)tile_m * g.n_store + n0 + c] = cmx[j];
+                g.stat_colsum[(size_t)tile_m * g.n_store + n0 + c] = tot;
+              }
+            }
+          }
+        }
       }
     }
     for (int u = tid; u < BM * (WP / 4); u += NT) {
@@ -611,6 +698,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       }
     }
   }
+  if ((ABL == 9 || ABL > 90) && g.dbg_ts != nullptr && lane == 0) {
+    unsigned long long* o = g.dbg_ts + ((size_t)blockIdx.x * (WAVES_M * WAVES_N) + wave) * 4;
+    o[0] = ts0;
+    o[1] = ts1;
+    o[2] = ts2;
+    o[3] = __builtin_readcyclecounter();
+  }
 }
 
 // ---- optional live profiling of one kernel symbol (tile config x conv/dense) with HIP events ----
@@ -623,6 +717,20 @@ struct GemmProfiler {
   long long dropped = 0;
   std::mutex mu;                // forwards may be in flight from several host threads / streams
 } g_prof;
+
+unsigned long long* g_dbg_ts = nullptr;   // tuning: opp_debug_timestamps()
+
+template <int BM, int BN, int WM, int WN, bool H2, int ABL = 9>
+int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // tuning only: conv kernel with phase time stamps
+  OppGemm g = g_in;
+  g.dbg_ts = g_dbg_ts;
+  const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float);
+  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, H2>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN)), dim3(WM * WN * 64), lds, stream, g);
+  OPP_CHECK_LAUNCH("opp_gemm_kernel(timed)");
+  return OPP_OK;
+}
 
 template <int ABL>
 int launch_ablate(const OppGemm& g, hipStream_t stream) {   // tuning only: 128x128 conv with parts removed
@@ -740,7 +848,16 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
     // (fp16x2: the MFMA phase is 5x shorter, depth 2 measured best on every layer)
     if (g.conv && g.K >= 768 && cfg == 0 && !g.h2) cfg = t0 <= 512 ? 11 : 10;
+    if (g.h2) {
+      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier) once they
+      // still give ~a workgroup per CU; 128x256 when N > 128 so the activation split is done once per row
+      const int t22 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 256);
+      const int t20 = opp_cdiv(g.M, 256) * opp_cdiv(g.n_store, 128);
+      if (g.n_store > 128 && t22 >= 200) cfg = 22;
+      else if (t20 >= 200) cfg = 20;
+    }
   }
+  OPP_CHECK_ARG(g.stat_rowmax == nullptr || (cfg == 0 && !g.h2), "gemm: fused softmax statistics need the fp32 128x128 tile");
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
   size_t slot = 0;
@@ -768,6 +885,13 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
     case 21: rc = launch_cfg<256, 128, 4, 2, 3>(g, stream); break;
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
+    case 23: rc = launch_cfg<256, 128, 2, 2>(g, stream); break;     // 4 waves, 128x64 per wave
+    case 24: rc = launch_cfg<256, 256, 2, 2>(g, stream); break;     // 4 waves, 128x128 per wave
+    case 120: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<256, 128, 4, 2, true>(g, stream) : launch_timed<256, 128, 4, 2, false>(g, stream); break;
+    case 121: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<128, 128, 2, 2, true>(g, stream) : launch_timed<128, 128, 2, 2, false>(g, stream); break;
+    case 191: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 91>(g, stream) : OPP_ERR_INVALID; break;   // no global loads
+    case 192: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 92>(g, stream) : OPP_ERR_INVALID; break;   // no LDS stores
+    case 193: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 93>(g, stream) : OPP_ERR_INVALID; break;   // no barrier
     case 101: rc = g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID; break;
     case 102: rc = g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID; break;
     case 103: rc = g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID; break;
@@ -778,6 +902,13 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   }
   if (rec) (void)hipEventRecord(g_prof.ev[slot + 1], stream);
   return rc;
+}
+
+// tuning: device buffer receiving 4 shader-clock stamps (entry, loop start, loop end, exit) per wave
+// of the timed conv variants (tile configs 120 / 121)
+extern "C" int opp_debug_timestamps(void* buf) {
+  g_dbg_ts = static_cast<unsigned long long*>(buf);
+  return OPP_OK;
 }
 
 // Live measurement of one GEMM kernel symbol with HIP events recorded on the launch stream

@@ -85,6 +85,7 @@ struct OppGemm {
   // three v_mfma_f32_32x32x16_f16 products per k16-step, fp32 accumulate (22-bit operand mantissas)
   int h2 = 0;
   const float* h2_inv = nullptr;   // device scalar: 1 / (power-of-two scale applied to W before the split), or null
+  unsigned long long* dbg_ts = nullptr;   // tuning builds (ABL 9): 4 shader-clock stamps per wave
   int xcd_swizzle = 1;
   int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
   // optional softmax statistics of the OUTPUT tile (score GEMM of the coarse matcher): per row

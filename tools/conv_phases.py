@@ -1,0 +1,51 @@
+"""Phase breakdown (prologue / K loop / epilogue, shader clocks) of the conv kernel from in-kernel time stamps.
+    python tools/conv_phases.py [--h2 1]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from onepose_plus_plus_amd import _lib  # noqa: E402
+
+CASES = [("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1), ("l1_out2a 3x3 196->196 @256", 256, 256, 224, 224, 3, 1),
+         ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1), ("layer3 3x3 256->256 @64", 64, 64, 256, 256, 3, 1)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--h2", type=int, default=1)
+    args = ap.parse_args()
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    for name, H, W, cin, cout, ks, stride in CASES:
+        x = torch.randn(H, W, cin, device="cuda")
+        w = torch.randn(cout, ks * ks * cin, device="cuda") * 0.02
+        if args.h2:
+            w2 = torch.empty_like(w)
+            _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack")
+            w = w2
+        y = torch.empty(H // stride, W // stride, cout, device="cuda")
+        bias = torch.randn(cout, device="cuda")
+        for cfg, bm, bn, waves in ((120, 256, 128, 8), (121, 128, 128, 4)) + (((191, 256, 128, 8), (192, 256, 128, 8), (193, 256, 128, 8)) if args.h2 else ()):
+            nb = -(-(H // stride) * (W // stride) // bm) * -(-cout // bn)
+            ts = torch.zeros(nb * waves * 4, dtype=torch.int64, device="cuda")
+            _lib.check(lib.opp_debug_timestamps(ts.data_ptr()), "ts")
+            for _ in range(3):
+                _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, w.data_ptr(), bias.data_ptr(), cout, ks, stride,
+                                               None, 0, 1, y.data_ptr(), cfg, args.h2, None, s), "conv")
+            torch.cuda.synchronize()
+            t = ts.view(nb, waves, 4).double().cpu()
+            pro, loop, epi = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2])
+            span = t[..., 3].max() - t[..., 0].min()
+            first_start = t[..., 0].min()
+            print("%-28s cfg%d blocks %4d  prologue %7.0f  loop %8.0f (%.0f/chunk)  epilogue %7.0f  | kernel span %8.0f clk, "
+                  "last block starts at +%.0f" % (name, cfg, nb, pro.mean(), loop.mean(), loop.mean() / (ks * ks * cin / 32),
+                                                  epi.mean(), span, t[..., 0].max() - first_start), flush=True)
+    _lib.check(lib.opp_debug_timestamps(None), "ts")
+
+
+if __name__ == "__main__":
+    main()
