@@ -54,9 +54,10 @@ def main():
     ap.add_argument("--thr", type=float, default=0.1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 GEMM comparison run")
     ap.add_argument("--precision", default=None, choices=["fp32", "fp16x2"],
                     help="GEMM arithmetic (default: the module default / OPP_GEMM_PRECISION)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "3")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
                          "2 Ray workers per GPU, inference_OnePosePlus.py:18-26); steps are split evenly")
     args = ap.parse_args()
@@ -95,8 +96,6 @@ def main():
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
-    if args.steps % n_streams:
-        raise SystemExit("--steps must be a multiple of --streams")
     models = [model]
     for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
         m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).to(dev)
@@ -140,7 +139,7 @@ def main():
 
         def worker(slot):
             torch.cuda.set_device(dev)
-            for i in range(n // n_streams):
+            for i in range(n // n_streams + (1 if slot < n % n_streams else 0)):     # exactly n forwards in total
                 out[slot] = step(i * n_streams + slot, slot)
             streams[slot].synchronize()
         th = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
@@ -198,6 +197,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    fp32_leg = None
+    if rank == 0 and world == 1 and precision != "fp32" and not args.no_fp32_leg:
+        # the same forwards with the exact-fp32 MFMA GEMMs, for reference beside the headline value
+        for m in models:
+            m.set_gemm_precision("fp32").to(dev)
+        for k in range(n_streams):
+            step(0, k)
+        torch.cuda.synchronize(dev)
+        n32 = min(args.steps, 30)
+        t1 = time.perf_counter()
+        run_steps(n32)
+        torch.cuda.synchronize(dev)
+        fp32_leg = {"value": round(n32 / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n32,
+                    "gemm_precision": "fp32"}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(cfg, make_state_dict(cfg, 0), args, make_inputs)
@@ -215,7 +229,7 @@ def main():
             "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
                                    "%d forward(s) in flight per GPU, one object per GPU"
                                    % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams),
-                       "streams_per_gpu": n_streams, "gemm_precision": precision,
+                       "streams_per_gpu": n_streams, "gemm_precision": precision, "fp32_gemm_leg": fp32_leg,
                        "matches_last_step": int(last["mconf"].numel()),
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),

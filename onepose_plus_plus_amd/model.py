@@ -139,7 +139,7 @@ def _validate_config(cfg):
 
 
 GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1}
-DEFAULT_GEMM_PRECISION = "fp32"
+DEFAULT_GEMM_PRECISION = "fp16x2"
 
 
 class OnePosePlus_model(nn.Module):

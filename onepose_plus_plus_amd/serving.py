@@ -18,11 +18,13 @@ from .model import OnePosePlus_model
 
 
 class MatcherPool:
-    def __init__(self, config, state_dict, device=None, n_streams=2):
+    def __init__(self, config, state_dict, device=None, n_streams=3, gemm_precision=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.models, self.streams = [], []
         for _ in range(max(1, int(n_streams))):
             m = OnePosePlus_model(config).eval()
+            if gemm_precision is not None:
+                m.set_gemm_precision(gemm_precision)
             m.load_state_dict(state_dict, strict=True)
             self.models.append(m.to(self.device))
             self.streams.append(torch.cuda.Stream(device=self.device))
