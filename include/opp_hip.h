@@ -158,6 +158,14 @@ int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stre
 int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
                    float* out, int rows, int C, void* stream);
 
+/* ---- query-image ingest ------------------------------------------------------
+ * 8-bit grayscale frame [h][src_stride] on the device -> cv2.resize(INTER_LINEAR, 8-bit fixed point)
+ * to [h_new][w_new] -> fp32 / 255 (read_grayscale + grayscale2tensor, src/utils/data_io.py:34-69,
+ * :105-106).  dst (fp32, row stride dst_stride floats; e.g. a pad_to canvas) and dst_u8 (the resized
+ * 8-bit image, packed) are both optional, at least one must be given. */
+int opp_image_ingest_u8(const unsigned char* src, int h, int w, int src_stride, int h_new, int w_new,
+                        float* dst, int dst_stride, unsigned char* dst_u8, void* stream);
+
 /* ---- pose from the matches (next row after the matcher) --------------------
  * PnP-RANSAC on the device: replaces ransac_PnP / cv2.solvePnPRansac(EPNP, 10000 iterations)
  * (src/utils/metric_utils.py:121-204) so the matches never leave the GPU.  pts2d [n][2] (pixels),

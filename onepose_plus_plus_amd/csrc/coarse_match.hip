@@ -110,84 +110,138 @@ __global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, in
 
 // ---- merge of the per-tile (max, sum exp) partials produced by the score GEMM epilogue -----------
 // rows: part [N][T] ; cols: part [T][L] ; out max / sum with the global max as reference
-__global__ void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
-                                 float* __restrict__ omax, float* __restrict__ osum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  float m = -INFINITY;
-  for (int t = 0; t < T; ++t) m = fmaxf(m, pmax[(size_t)i * T + t]);
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += psum[(size_t)i * T + t] * expf(pmax[(size_t)i * T + t] - m);
-  omax[i] = m;
-  osum[i] = s;
+// rows: 8 lanes per row, lane u takes tiles u, u+8, ...; pairwise combine in a fixed butterfly order
+__global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
+                                                        float* __restrict__ omax, float* __restrict__ osum) {
+  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int u = threadIdx.x & 7;
+  float m = -INFINITY, s = 0.f;
+  if (i < N) {
+    for (int t = u; t < T; t += 8) m = fmaxf(m, pmax[(size_t)i * T + t]);
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (i < N) {
+    for (int t = u; t < T; t += 8) s += psum[(size_t)i * T + t] * expf(pmax[(size_t)i * T + t] - m);
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) s += __shfl_xor(s, o, 64);
+  if (i < N && u == 0) {
+    omax[i] = m;
+    osum[i] = s;
+  }
 }
-__global__ void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
-                                 float* __restrict__ omax, float* __restrict__ osum) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= L) return;
+// columns: block = 64 columns x 4 tile groups (group g takes tiles g, g+4, ...), combined through LDS in group order
+__global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
+                                                        float* __restrict__ omax, float* __restrict__ osum) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float m = -INFINITY;
-  for (int t = 0; t < T; ++t) m = fmaxf(m, pmax[(size_t)t * L + j]);
+  if (j < L)
+    for (int t = gq; t < T; t += 4) m = fmaxf(m, pmax[(size_t)t * L + j]);
+  red[gq][c] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
+  __syncthreads();
   float s = 0.f;
-  for (int t = 0; t < T; ++t) s += psum[(size_t)t * L + j] * expf(pmax[(size_t)t * L + j] - m);
-  omax[j] = m;
-  osum[j] = s;
+  if (j < L)
+    for (int t = gq; t < T; t += 4) s += psum[(size_t)t * L + j] * expf(pmax[(size_t)t * L + j] - m);
+  red[gq][c] = s;
+  __syncthreads();
+  if (gq == 0 && j < L) {
+    omax[j] = m;
+    osum[j] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+  }
+}
+// column max over `chunks` partial rows [chunks][L] (max is order-independent): 64 columns x 4 chunk groups
+__global__ __launch_bounds__(256) void col_max_reduce_kernel(const float* __restrict__ part, int chunks, int L,
+                                                             float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float m = -INFINITY;
+  if (j < L)
+    for (int t = gq; t < chunks; t += 4) m = fmaxf(m, part[(size_t)t * L + j]);
+  red[gq][c] = m;
+  __syncthreads();
+  if (gq == 0 && j < L) out[j] = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
 }
 
 // ---- conf = colsoftmax * rowsoftmax, in place; per-row max / first argmax / tie count --------
+// Block = 4 waves x kConfRows rows each (wave per row at a time).  With col_part != nullptr the block also
+// keeps the column maxima of its rows in LDS (confidences are >= +0, so an unsigned max on the bit patterns is
+// the float max, and max is order-independent -> deterministic) and writes them as one partial row.
+constexpr int kConfRows = 4;
 template <int VEC>
 __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N, int L,
                                                    const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                    const float* __restrict__ cmax, const float* __restrict__ csum,
                                                    float* __restrict__ row_cmax, int* __restrict__ row_arg,
-                                                   int* __restrict__ row_ties) {
+                                                   int* __restrict__ row_ties, float* __restrict__ col_part) {
+  extern __shared__ unsigned colmax_bits[];
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= N) return;
-  float* s = S + (size_t)row * L;
-  const float rm = rmax[row], rs = rsum[row];
-  float best = -1.f;
-  int arg = 0x7fffffff;
-  for (int j = lane * VEC; j < L; j += 64 * VEC) {
-    float v[VEC], cm[VEC], cs[VEC];
-    Ld<VEC>::load(s + j, v);
-    Ld<VEC>::load(cmax + j, cm);
-    Ld<VEC>::load(csum + j, cs);
+  if (col_part != nullptr) {
+    for (int j = threadIdx.x; j < L; j += 256) colmax_bits[j] = 0u;
+    __syncthreads();
+  }
+  for (int rr = 0; rr < kConfRows; ++rr) {
+    const int row = (blockIdx.x * kConfRows + rr) * 4 + (threadIdx.x >> 6);
+    if (row >= N) break;      // wave-uniform
+    float* s = S + (size_t)row * L;
+    const float rm = rmax[row], rs = rsum[row];
+    float best = -1.f;
+    int arg = 0x7fffffff;
+    for (int j = lane * VEC; j < L; j += 64 * VEC) {
+      float v[VEC], cm[VEC], cs[VEC];
+      Ld<VEC>::load(s + j, v);
+      Ld<VEC>::load(cmax + j, cm);
+      Ld<VEC>::load(csum + j, cs);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
-      const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
-      const float c = pc * pr;
-      v[e] = c;
-      if (c > best) {
-        best = c;
-        arg = j + e;
+      for (int e = 0; e < VEC; ++e) {
+        const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
+        const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
+        const float c = pc * pr;
+        v[e] = c;
+        if (c > best) {
+          best = c;
+          arg = j + e;
+        }
+      }
+      Ld<VEC>::store(s + j, v);
+      if (col_part != nullptr) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) atomicMax(&colmax_bits[j + e], __float_as_uint(v[e]));
       }
     }
-    Ld<VEC>::store(s + j, v);
-  }
-  // wave arg-max, ties to the lowest column
+    // wave arg-max, ties to the lowest column
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ob = __shfl_xor(best, o, 64);
-    const int oa = __shfl_xor(arg, o, 64);
-    if (ob > best || (ob == best && oa < arg)) {
-      best = ob;
-      arg = oa;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) {
+        best = ob;
+        arg = oa;
+      }
+    }
+    int ties = 0;
+    for (int j = lane * VEC; j < L; j += 64 * VEC) {
+      float v[VEC];
+      Ld<VEC>::load(s + j, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) ties += (v[e] == best) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
+    if (lane == 0) {
+      row_cmax[row] = best;
+      row_arg[row] = arg;
+      row_ties[row] = ties;
     }
   }
-  int ties = 0;
-  for (int j = lane * VEC; j < L; j += 64 * VEC) {
-    float v[VEC];
-    Ld<VEC>::load(s + j, v);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) ties += (v[e] == best) ? 1 : 0;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
-  if (lane == 0) {
-    row_cmax[row] = best;
-    row_arg[row] = arg;
-    row_ties[row] = ties;
+  if (col_part != nullptr) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < L; j += 256) col_part[(size_t)blockIdx.x * L + j] = __uint_as_float(colmax_bits[j]);
   }
 }
 
@@ -273,7 +327,7 @@ size_t opp_coarse_match_stats_floats(int N, int L) {
 }
 
 size_t opp_coarse_match_scratch_floats(int N, int L) {
-  const int chunks = opp_cdiv(N, 128);
+  const int chunks = opp_cdiv(N, 128) > opp_cdiv(N, 4 * kConfRows) ? opp_cdiv(N, 128) : opp_cdiv(N, 4 * kConfRows);
   const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
   // rmax, rsum, row_cmax [Np] ; row_arg, row_ties [Np] (int) ; cmax, csum, col_cmax [Lp] ; partials [chunks][L]
   return 5 * Np + 3 * Lp + (size_t)chunks * L + 64;
@@ -304,8 +358,8 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
     const float* rps = rpm + (size_t)N * tn;
     const float* cpm = rps + (size_t)N * tn;
     const float* cps = cpm + (size_t)tm * L;
-    hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(N, 256)), dim3(256), 0, stream, rpm, rps, N, tn, rmax, rsum);
-    hipLaunchKernelGGL(col_merge_kernel, lgrid, dim3(256), 0, stream, cpm, cps, L, tm, cmax, csum);
+    hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(N, 32)), dim3(256), 0, stream, rpm, rps, N, tn, rmax, rsum);
+    hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, cpm, cps, L, tm, cmax, csum);
   } else {
     if (vec4) hipLaunchKernelGGL(row_stats_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
     else hipLaunchKernelGGL(row_stats_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
@@ -314,10 +368,20 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
     hipLaunchKernelGGL(col_partial_kernel<1>, cgrid, dim3(256), 0, stream, S, N, L, 128, cmax, part);
     hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum);
   }
-  if (vec4) hipLaunchKernelGGL(conf_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
-  else hipLaunchKernelGGL(conf_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties);
-  hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
-  hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax);
+  // conf in place + per-row arg-max; the column maxima of the confidences come out of the same pass as one
+  // partial row per block when the [L] LDS array fits the default dynamic-LDS limit, else from a second sweep
+  const int cblocks = opp_cdiv(N, 4 * kConfRows);
+  const bool fuse_cmax = (size_t)L * 4 <= 64 * 1024;
+  const size_t conf_lds = fuse_cmax ? (size_t)L * 4 : 0;
+  float* cpart = fuse_cmax ? part : nullptr;
+  if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  if (fuse_cmax) {
+    hipLaunchKernelGGL(col_max_reduce_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, part, cblocks, L, col_cmax);
+  } else {
+    hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax);
+  }
   hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, S, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr,
                      border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
   OPP_CHECK_LAUNCH("coarse match kernels");
