@@ -22,6 +22,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// wave64 sum on the DPP path (no LDS round trips): quad butterflies, half-row / row mirrors, then the two
+// row broadcasts leave the total in lane 63; fixed order, every lane returns the same value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim (C = 64*VPT), one wave per row, optional residual add:
 //   out = (res ? res : 0) + (x - mean) / sqrt(var + eps) * gamma + beta
@@ -40,41 +57,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (row0 >= rows) return;
   float v[RPW][VPT], rv[RPW][VPT], gm[VPT], bt[VPT];
+  typedef float vec_t __attribute__((ext_vector_type(VPT)));     // one 8 / 16 B access per lane and row
+  auto ldv = [](const float* p, float (&dst)[VPT]) {
+    const vec_t t = *reinterpret_cast<const vec_t*>(p);
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) {
-    gm[i] = gamma[lane * VPT + i];
-    bt[i] = beta[lane * VPT + i];
-  }
+    for (int i = 0; i < VPT; ++i) dst[i] = t[i];
+  };
+  ldv(gamma + lane * VPT, gm);
+  ldv(beta + lane * VPT, bt);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     const bool ok = row0 + r < rows;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      v[r][i] = ok ? x[(size_t)(row0 + r) * ldx + lane * VPT + i] : 0.f;
-      rv[r][i] = (ok && res) ? res[(size_t)(row0 + r) * ldres + lane * VPT + i] : 0.f;
+      v[r][i] = 0.f;
+      rv[r][i] = 0.f;
+    }
+    if (ok) ldv(x + (size_t)(row0 + r) * ldx + lane * VPT, v[r]);
+    if (ok && res) ldv(res + (size_t)(row0 + r) * ldres + lane * VPT, rv[r]);
+  }
+  // the four rows' reductions advance in lock step: four independent shuffle chains per step
+  float sm[RPW], mean[RPW], rstd[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    sm[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) sm[r] += v[r][i];
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) sm[r] = wave_sum_dpp(sm[r]);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    mean[r] = sm[r] / (float)C;
+    sm[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+      const float d = v[r][i] - mean[r];
+      sm[r] += d * d;
     }
   }
 #pragma unroll
+  for (int r = 0; r < RPW; ++r) sm[r] = wave_sum_dpp(sm[r]);
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) rstd[r] = 1.0f / sqrtf(sm[r] / (float)C + eps);
+#pragma unroll
   for (int r = 0; r < RPW; ++r) {
-    if (row0 + r >= rows) break;
-    float s = 0.f;
+    if (row0 + r < rows) {
+      vec_t o;
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) s += v[r][i];
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      const float d = v[r][i] - mean;
-      q += d * d;
-    }
-    const float var = wave_sum(q) / (float)C;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    float* orow = out + (size_t)(row0 + r) * ldo + lane * VPT;
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-      float y = (v[r][i] - mean) * rstd * gm[i] + bt[i];
-      if (res) y = rv[r][i] + y;
-      orow[i] = y;
+      for (int i = 0; i < VPT; ++i) {
+        float y = (v[r][i] - mean[r]) * rstd[r] * gm[i] + bt[i];
+        if (res) y = rv[r][i] + y;
+        o[i] = y;
+      }
+      *reinterpret_cast<vec_t*>(out + (size_t)(row0 + r) * ldo + lane * VPT) = o;
     }
   }
 }
@@ -217,17 +253,19 @@ __global__ __launch_bounds__(C) void linattn_apply_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------------------
 // Coarse level (one segment per stream, C = 256, D = 32): KV / Ksum on the fp32 MFMA.
-// One block = one chunk of 128 tokens of ONE stream, one wave per head:
+// One block = one wave = one head of one chunk of kPairChunk tokens of ONE stream (grid = chunks x 8 heads,
+// >= 4 waves per CU at 5k points: the reduction is bound by loads in flight, not by the MFMA):
 //   KV_h[d][v] += sum_t K[t][h*32+d] * V[t][h*32+v]   ==  mfma_32x32x2(A = K^T, B = V), 2 tokens / MFMA
 // Both streams are covered by one launch; partials [chunk][h][d][v] are summed in fixed order
 // by linattn_reduce_pair_kernel (deterministic).
 // ---------------------------------------------------------------------------------------
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(512) void linattn_kv_mfma_kernel(const float* __restrict__ qkv, int ld, int len0, int len1,
+constexpr int kPairChunk = 64;
+__global__ __launch_bounds__(64) void linattn_kv_mfma_kernel(const float* __restrict__ qkv, int ld, int len0, int len1,
                                                               int chunks0, float* __restrict__ kv_part,
                                                               float* __restrict__ ks_part) {
-  constexpr int C = 256, CHUNK = 128;
+  constexpr int C = 256, CHUNK = kPairChunk;
   const int chunk = blockIdx.x;
   const int stream = chunk >= chunks0 ? 1 : 0;
   const int cidx = stream ? chunk - chunks0 : chunk;
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(512) void linattn_kv_mfma_kernel(const float* __res
   const int tok0 = stream ? len0 : 0;
   const int s_begin = cidx * CHUNK;
   const int s_end = min(seg_len, s_begin + CHUNK);
-  const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, h = blockIdx.y;
   const int half = lane >> 5, l31 = lane & 31;
   const float* kbase = qkv + (size_t)tok0 * ld + C + h * 32 + l31;
   const float* vbase = kbase + C;
@@ -268,35 +306,42 @@ __global__ __launch_bounds__(512) void linattn_kv_mfma_kernel(const float* __res
   if (half == 0) ks_part[(size_t)chunk * C + h * 32 + l31] = tot;
 }
 
-// out_kv [2][8192], out_ks [2][256] ; blockIdx.y = stream
+// out_kv [2][8192], out_ks [2][256] ; blockIdx.y = stream.  Block = 64 outputs x 4 chunk groups (group g sums
+// chunks g, g+4, ... in order; the four group sums are added in group order): fixed order, 4x shorter chains.
 __global__ __launch_bounds__(256) void linattn_reduce_pair_kernel(const float* __restrict__ kv_part,
                                                                  const float* __restrict__ ks_part, int chunks0,
                                                                  int chunks1, float* __restrict__ out_kv,
                                                                  float* __restrict__ out_ks) {
   constexpr int KV = 8192, C = 256;
+  __shared__ float red[4][64];
   const int stream = blockIdx.y;
   const int c_begin = stream ? chunks0 : 0;
   const int c_end = stream ? chunks0 + chunks1 : chunks0;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int e = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float s = 0.f;
   if (i < KV) {
-    float s = 0.f;
-    for (int c = c_begin; c < c_end; ++c) s += kv_part[(size_t)c * KV + i];
-    out_kv[stream * KV + i] = s;
+    for (int c = c_begin + gq; c < c_end; c += 4) s += kv_part[(size_t)c * KV + i];
   } else if (i < KV + C) {
-    const int j = i - KV;
-    float s = 0.f;
-    for (int c = c_begin; c < c_end; ++c) s += ks_part[(size_t)c * C + j];
-    out_ks[stream * C + j] = s;
+    for (int c = c_begin + gq; c < c_end; c += 4) s += ks_part[(size_t)c * C + (i - KV)];
+  }
+  red[gq][e] = s;
+  __syncthreads();
+  if (gq == 0) {
+    const float tot = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (i < KV) out_kv[stream * KV + i] = tot;
+    else if (i < KV + C) out_ks[stream * C + (i - KV)] = tot;
   }
 }
 
 // apply for both streams in one launch (C = 256, D = 32, one segment per stream)
+constexpr int kApplyChunk = 8;
 __global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __restrict__ qkv, int ld,
                                                                 const float* __restrict__ kv,
                                                                 const float* __restrict__ ks, int cross,
                                                                 float* __restrict__ out, int ldo, int len0, int len1,
                                                                 int chunks0, float eps) {
-  constexpr int C = 256, D = 32, TB = 8, CHUNK = 32;
+  constexpr int C = 256, D = 32, TB = 8, CHUNK = kApplyChunk;   // one LDS stage per block; occupancy hides the latency
   __shared__ __attribute__((aligned(16))) float qsh[TB][C];
   const int t = threadIdx.x;
   const int h = t / D, v = t % D;
@@ -353,6 +398,12 @@ __global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __
 int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res,
                   int ldres, float* out, int ldo, int rows, int C, float eps, hipStream_t stream) {
   if (rows <= 0) return OPP_OK;
+  {
+    const int vb = (C / 64) * 4;   // bytes per lane access
+    auto al = [&](const void* p) { return (reinterpret_cast<uintptr_t>(p) % vb) == 0; };
+    OPP_CHECK_ARG(al(x) && al(gamma) && al(beta) && al(out) && (!res || al(res)) && (ldx * 4) % vb == 0 && (ldo * 4) % vb == 0 &&
+                      (!res || (ldres * 4) % vb == 0), "layernorm: operands must be %d-byte aligned", vb);
+  }
   dim3 grid(opp_cdiv(rows, 16)), block(256);
   if (C == 256)
     hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, ldx, gamma, beta, res, ldres, out, ldo, rows, eps);
@@ -420,25 +471,25 @@ int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks,
 
 // ---- coarse level: both streams in three launches ------------------------------------------
 size_t opp_linattn_pair_scratch_floats(int len0, int len1) {
-  const size_t chunks = (size_t)opp_cdiv(len0, 128) + opp_cdiv(len1, 128);
+  const size_t chunks = (size_t)opp_cdiv(len0, kPairChunk) + opp_cdiv(len1, kPairChunk);
   return chunks * (8192 + 256);
 }
 
 // qkv [len0+len1][ld] with Q | K | V column blocks of 256.  kv [2][8192], ks [2][256].
 int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
                         hipStream_t stream) {
-  const int c0 = opp_cdiv(len0, 128), c1 = opp_cdiv(len1, 128);
+  const int c0 = opp_cdiv(len0, kPairChunk), c1 = opp_cdiv(len1, kPairChunk);
   float* kvp = scratch;
   float* ksp = scratch + (size_t)(c0 + c1) * 8192;
-  hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1), dim3(512), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
-  hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 256), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
+  hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(64), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
+  hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 64), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
   OPP_CHECK_LAUNCH("linattn_kv_pair");
   return OPP_OK;
 }
 
 int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
                            int len0, int len1, float eps, hipStream_t stream) {
-  const int c0 = opp_cdiv(len0, 32), c1 = opp_cdiv(len1, 32);
+  const int c0 = opp_cdiv(len0, kApplyChunk), c1 = opp_cdiv(len1, kApplyChunk);
   hipLaunchKernelGGL(linattn_apply_pair_kernel, dim3(c0 + c1), dim3(256), 0, stream, qkv, ld, kv, ks, cross, out, ldo, len0, len1,
                      c0, eps);
   OPP_CHECK_LAUNCH("linattn_apply_pair_kernel");
