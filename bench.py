@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 GEMM comparison run")
-    ap.add_argument("--precision", default=None, choices=["fp32", "fp16x2"],
+    ap.add_argument("--precision", default=None, choices=["fp32", "fp16x2", "fp16x2_all"],
                     help="GEMM arithmetic (default: the module default / OPP_GEMM_PRECISION)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "3")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
@@ -87,7 +87,7 @@ def main():
     if args.precision:
         model.set_gemm_precision(args.precision)
     precision = model.gemm_precision
-    DOMINANT_CFG, DOMINANT_CONV, DOMINANT_NAME, PEAK = DOMINANT[precision]
+    DOMINANT_CFG, DOMINANT_CONV, DOMINANT_NAME, PEAK = DOMINANT["fp32" if precision == "fp32" else "fp16x2"]
     sd = make_state_dict(cfg, 0) if rank == 0 else None
     model = model.to(dev)
     if dist is not None:

@@ -708,6 +708,8 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   const int C = c->cfg.coarse_d_model, L = hc * wc;
   float* scratch = a.f(opp_coarse_match_scratch_floats(n, L));
   float* stats = a.f(opp_coarse_match_stats_floats(n, L));
+  const bool h2 = c->cfg.gemm_precision >= 2;          // score GEMM on the fp16x2 path as well
+  float* f2_split = h2 ? a.f((size_t)L * C) : nullptr;
   if (!a.ok) {
     opp_set_error("coarse_match: workspace too small");
     return OPP_ERR_WORKSPACE;
@@ -735,6 +737,11 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
     g.stat_colmax = g.stat_rowsum + (size_t)n * tn;
     g.stat_colsum = g.stat_colmax + tm * (size_t)L;
   }
+  if (h2) {   // the image tokens are the "weight" operand here: split them once per image (4 MB), unscaled
+    OPP_TRY(opp_h2_split(f2, f2_split, (size_t)L * C, nullptr, s));
+    g.W = f2_split;
+    g.h2 = 1;
+  }
   OPP_TRY(opp_gemm_launch_cfg(g, 0, s));   // 128x128 tiles: the partial layout above assumes them
   return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, stats, scratch, i_ids, j_ids,
                                  mconf, mkpts_c, mkpts_3d, count, s);
@@ -745,7 +752,8 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
 extern "C" size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n, int L) {
   (void)ctx;
   return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) +
-         opp_align(opp_coarse_match_stats_floats(n, L) * sizeof(float)) + 1024;
+         opp_align(opp_coarse_match_stats_floats(n, L) * sizeof(float)) +
+         opp_align((size_t)L * 256 * sizeof(float)) + 1024;
 }
 
 extern "C" int opp_coarse_match(opp_ctx* ctx, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts,

@@ -480,6 +480,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   const bool vec_ok = g.vec_epilogue != 0;
   // fp16x2: the weight matrix was pre-scaled by a power of two (its fp16 lo halves stay normal); undo, exactly
   const float h2_inv = (H2 && g.h2_inv != nullptr) ? *g.h2_inv : 1.f;
+  if (H2 || scale_on) {   // output scaling once, in place (the statistics below reuse the scaled values)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
+          acc[i][j][r] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
+        }
+  }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     __syncthreads();   // operand buffers (or the previous pass) are no longer read
@@ -492,8 +503,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int lr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
-            Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
+            Cs[lr * CS + wn * JP * 32 + jj * 32 + l31] = acc[i][j][r];
           }
         }
       }
@@ -549,10 +559,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           }
         }
         {  // columns: straight from the accumulators (lane = column), same scaled value as stored
-          auto sval = [&](int i, int j, int r) -> float {
-            const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
-            return scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
-          };
+          auto sval = [&](int i, int j, int r) -> float { return acc[i][j][r]; };
           auto rvalid = [&](int i, int r) -> bool {
             return wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half < nrows;
           };
@@ -857,7 +864,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       else if (t20 >= 200) cfg = 20;
     }
   }
-  OPP_CHECK_ARG(g.stat_rowmax == nullptr || (cfg == 0 && !g.h2), "gemm: fused softmax statistics need the fp32 128x128 tile");
+  OPP_CHECK_ARG(g.stat_rowmax == nullptr || cfg == 0, "gemm: fused softmax statistics need the 128x128 tile");
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
   size_t slot = 0;

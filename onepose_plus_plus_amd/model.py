@@ -138,8 +138,8 @@ def _validate_config(cfg):
         raise NotImplementedError()
 
 
-GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1}
-DEFAULT_GEMM_PRECISION = "fp16x2"
+GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 2}
+DEFAULT_GEMM_PRECISION = "fp16x2_all"
 
 
 class OnePosePlus_model(nn.Module):

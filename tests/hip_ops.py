@@ -101,7 +101,7 @@ def layer_norm(x, g, b, res=None):
     return out.cpu()
 
 
-PRECISIONS = ("fp32", "fp16x2")
+PRECISIONS = ("fp32", "fp16x2", "fp16x2_all")
 
 
 def make_model(cfg, sd, precision=None):

@@ -14,7 +14,7 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
 
 
-@pytest.fixture(scope="module", params=["fp32", "fp16x2"])
+@pytest.fixture(scope="module", params=["fp32", "fp16x2", "fp16x2_all"])
 def small(request):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
@@ -75,7 +75,7 @@ def test_matcher_vs_golden(small, name):
     from tests import hip_ops as ops
     from onepose_plus_plus_amd.synthetic import make_state_dict
     cfg, f3d, f2d, data = H.matcher_setup(name)
-    model0 = ops.make_model(cfg, make_state_dict(cfg, 0))      # thr / border_rm come from cfg
+    model0 = ops.make_model(cfg, make_state_dict(cfg, 0), small[3].gemm_precision)      # thr / border_rm come from cfg
     got = ops.coarse_match(model0, f3d[0], f2d[0], tuple(data["q_hw_c"]), data["keypoints3d"][0], 8.0,
                            data["query_image_scale"][0])
     gold = H.load_golden(name)
@@ -96,7 +96,8 @@ def test_fine_vs_golden(small, name):
                            where=name)
 
 
-def test_matcher_exact_ties_follow_reference_rules():
+@pytest.mark.parametrize("precision", ["fp32", "fp16x2_all"])
+def test_matcher_exact_ties_follow_reference_rules(precision):
     """Duplicated image cells (tie inside a row -> first column wins) and duplicated 3D points
     (both rows are reported with the same cell), coarse_matching.py:158-172 / quirk q9."""
     from oracle import onepose_oracle as O
@@ -120,7 +121,7 @@ def test_matcher_exact_ties_follow_reference_rules():
     kpts = torch.rand(1, N, 3, generator=g) - 0.5
     data = {"q_hw_i": torch.Size([128, 192]), "q_hw_c": torch.Size(hw_c), "keypoints3d": kpts}
     O.coarse_matching(f3d[None], f2d[None], data, cfg["coarse_matching"])
-    model = ops.make_model(cfg, make_state_dict(cfg, 0))
+    model = ops.make_model(cfg, make_state_dict(cfg, 0), precision)
     got = ops.coarse_match(model, f3d, f2d, hw_c, kpts[0], 8.0, None)
     ref_i, ref_j = data["i_ids"].tolist(), data["j_ids"].tolist()
     assert 0 in ref_i and ref_j[ref_i.index(0)] == min(a, b)          # the tie resolves to the first cell
