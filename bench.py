@@ -34,12 +34,16 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (32x32x16)
-# dominant kernel per GEMM precision: (tile cfg, conv, name, peak in ALGORITHMIC TFLOP/s)
-DOMINANT = {
-    "fp32": (11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", PEAK_F32_MFMA_TFLOPS),
-    # three fp16 MFMA products per algorithmic multiply-add -> a third of the fp16 dense peak
-    "fp16x2": (20, 1, "opp_gemm_kernel<256,128,4,2,conv,depth2,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv)",
-               PEAK_F16_MFMA_TFLOPS / 3.0),
+# GEMM kernel symbols profiled per precision: (tile cfg, conv, name, peak in ALGORITHMIC TFLOP/s).  The one with
+# the largest total time per forward is reported as `roofline`, the rest under `roofline.other_kernels`.
+_P32 = PEAK_F32_MFMA_TFLOPS
+_P16 = PEAK_F16_MFMA_TFLOPS / 3.0   # three fp16 MFMA products per algorithmic multiply-add
+SYMBOLS = {
+    "fp32": [(11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", _P32, "128, 128, 2, 2, true, 0, 4, false"),
+             (1, 1, "opp_gemm_kernel<64,128,2,2,conv> (fp32 MFMA implicit-GEMM conv)", _P32, "64, 128, 2, 2, true, 0, 2, false")],
+    "fp16x2": [(20, 1, "opp_gemm_kernel<256,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P16, "256, 128, 4, 2, true, 0, 2, true"),
+               (1, 1, "opp_gemm_kernel<64,128,2,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv)", _P16, "64, 128, 2, 2, true, 0, 2, true"),
+               (22, 1, "opp_gemm_kernel<128,256,2,4,conv,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P16, "128, 256, 2, 4, true, 0, 2, true")],
 }
 
 
@@ -87,7 +91,7 @@ def main():
     if args.precision:
         model.set_gemm_precision(args.precision)
     precision = model.gemm_precision
-    DOMINANT_CFG, DOMINANT_CONV, DOMINANT_NAME, PEAK = DOMINANT["fp32" if precision == "fp32" else "fp16x2"]
+    symbols = SYMBOLS["fp32" if precision == "fp32" else "fp16x2"]
     sd = make_state_dict(cfg, 0) if rank == 0 else None
     model = model.to(dev)
     if dist is not None:
@@ -160,38 +164,56 @@ def main():
     lib = _lib.load()
     prof = (not args.no_roofline) and rank == 0 and world == 1
     prof_in_timed = prof and n_streams == 1
+
+    def prof_stop():
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
+        return ms.value, fl.value, n.value
+
     barrier()
     if prof_in_timed:
-        _lib.check(lib.opp_profile_start(DOMINANT_CFG, DOMINANT_CONV, args.steps * 8), "profile_start")
+        _lib.check(lib.opp_profile_start(symbols[0][0], symbols[0][1], args.steps * 8), "profile_start")
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     roof = None
-    if prof and not prof_in_timed:
-        # With several forwards in flight the kernels of different streams share the CUs, so a
-        # kernel's own launch duration is only meaningful on its own: time the dominant kernel in
-        # a single-stream pass of the same steps right after the timed region.
-        _lib.check(lib.opp_profile_start(DOMINANT_CFG, DOMINANT_CONV, args.steps * 8), "profile_start")
-        for i in range(args.steps):
-            step(i, 0)
-        torch.cuda.synchronize(dev)
     if prof:
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
-        if n.value > 0 and ms.value > 0:
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic_dominant_kernel%s.json" % ("" if precision == "fp32" else "_" + precision))
+        # HIP events recorded by the library on the launch stream around every launch of one kernel symbol.
+        # With several forwards in flight kernels of different streams share the CUs, so a kernel's own launch
+        # duration is only meaningful on its own: the symbols are then timed in single-stream passes of the
+        # same steps right after the timed region (`measured` says which).
+        meas = []
+        for si, (cfg_id, conv, name, peak, tmpl) in enumerate(symbols):
+            if si == 0 and prof_in_timed:
+                ms, fl, n = prof_stop()
+                how = "timed region"
+                nsteps = args.steps
+            else:
+                nsteps = min(args.steps, 40)
+                _lib.check(lib.opp_profile_start(cfg_id, conv, nsteps * 8), "profile_start")
+                for i in range(nsteps):
+                    step(i, 0)
+                torch.cuda.synchronize(dev)
+                ms, fl, n = prof_stop()
+                how = "single-stream pass of %d steps after the timed region" % nsteps
+            if n > 0 and ms > 0:
+                ach = fl / (ms * 1e-3) / 1e12
+                meas.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                             "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "symbol": tmpl,
+                             "measured": "HIP events on the launch stream, " + how,
+                             "launches": n, "launches_per_step": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
+                             "us_per_step": round(ms * 1e3 / nsteps, 1), "alg_gflop_per_launch": round(fl / n / 1e9, 3)})
+        if meas:
+            meas.sort(key=lambda m: -m["us_per_step"])
+            roof = meas[0]
+            tpath = os.path.join(ROOT, "profiles", "traffic_gemm_symbols_%s.json" % ("fp32" if precision == "fp32" else "fp16x2"))
             if os.path.exists(tpath):     # HBM bytes per launch from the committed rocprofv3 --pmc passes
                 with open(tpath) as f:
-                    traffic = json.load(f)
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK, 4), "traffic": traffic, "kernel": DOMINANT_NAME,
-                    "measured": "HIP events on the launch stream, " + ("timed region" if prof_in_timed else
-                                "single-stream pass of the same steps after the timed region"),
-                    "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                    "alg_gflop_per_launch": round(fl.value / n.value / 1e9, 3)}
+                    tr = json.load(f)
+                for m in meas:
+                    m["traffic"] = tr.get(m["symbol"])
+            roof["other_kernels"] = meas[1:]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -860,8 +860,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       // still give ~a workgroup per CU; 128x256 when N > 128 so the activation split is done once per row
       const int t22 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 256);
       const int t20 = opp_cdiv(g.M, 256) * opp_cdiv(g.n_store, 128);
-      if (g.n_store > 128 && t22 >= 200) cfg = 22;
-      else if (t20 >= 200) cfg = 20;
+      static const int big_env = getenv("OPP_H2_BIG_TILES") ? atoi(getenv("OPP_H2_BIG_TILES")) : 1;   // tuning knob
+      if (big_env && g.n_store > 128 && t22 >= 200) cfg = 22;
+      else if (big_env && t20 >= 200) cfg = 20;
     }
   }
   OPP_CHECK_ARG(g.stat_rowmax == nullptr || cfg == 0, "gemm: fused softmax statistics need the 128x128 tile");

@@ -2,7 +2,7 @@
 tools/pmc_bench.sh.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B:
 MI355X_MICROARCH.md §HBM); both counters are in KiB.
 
-    python tools/pmc_traffic_summary.py gpurun_out/pmc_bench profiles/r01_pmc_hbm_traffic.csv
+    python tools/pmc_traffic_summary.py gpurun_out/pmc_bench profiles/r01_pmc_hbm_traffic.csv [profiles/traffic_gemm_symbols.json]
 """
 import collections
 import csv
@@ -33,17 +33,19 @@ def main(d, out):
         wr.writerow(["Kernel", "Launches", "FetchBytesPerLaunch(x2 corrected)", "WriteBytesPerLaunch"])
         for r in rows:
             wr.writerow([r[0], r[1], "%.0f" % r[2], "%.0f" % r[3]])
-    dom = [r for r in rows if "opp_gemm_kernel<128, 128, 2, 2, true" in r[0]]
-    dom.sort(key=lambda r: -r[1])
-    if dom:
-        k, n, fb, wb = dom[0]
-        js = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
-              "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
-              "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py; FETCH x2 gfx950 correction"}
-        with open(os.path.join(os.path.dirname(out), "traffic_dominant_kernel.json"), "w") as f:
-            json.dump(js, f)
-        print(js)
-
+    # per GEMM symbol (template argument string) -> bytes per launch, read by bench.py's roofline leg
+    sym = {}
+    for k, n, fb, wb in rows:
+        if "opp_gemm_kernel<" in k:
+            t = k[k.find("<") + 1:k.find(">")]
+            sym[t] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+                      "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
+                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py; FETCH x2 gfx950 correction"}
+    jpath = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(out), "traffic_gemm_symbols.json")
+    with open(jpath, "w") as f:
+        json.dump(sym, f, indent=1)
+    for t in sym:
+        print(t, sym[t]["hbm_bytes_per_launch"])
 
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
