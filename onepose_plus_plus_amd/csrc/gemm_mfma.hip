@@ -863,6 +863,8 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       static const int big_env = getenv("OPP_H2_BIG_TILES") ? atoi(getenv("OPP_H2_BIG_TILES")) : 1;   // tuning knob
       if (big_env && g.n_store > 128 && t22 >= 200) cfg = 22;
       else if (big_env && t20 >= 200) cfg = 20;
+      else if (big_env && t0 >= 200) cfg = 25;      // 128x128 on 8 waves (32x64 per wave): the M ~ 16k layers, +11 % over 64x128
+      else if (big_env && t1 >= 512) cfg = 26;      // 64x128 on 8 waves
     }
   }
   OPP_CHECK_ARG(g.stat_rowmax == nullptr || cfg == 0, "gemm: fused softmax statistics need the 128x128 tile");
@@ -894,6 +896,8 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 21: rc = launch_cfg<256, 128, 4, 2, 3>(g, stream); break;
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
     case 23: rc = launch_cfg<256, 128, 2, 2>(g, stream); break;     // 4 waves, 128x64 per wave
+    case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
+    case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 24: rc = launch_cfg<256, 256, 2, 2>(g, stream); break;     // 4 waves, 128x128 per wave
     case 120: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<256, 128, 4, 2, true>(g, stream) : launch_timed<256, 128, 4, 2, false>(g, stream); break;
     case 121: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<128, 128, 2, 2, true>(g, stream) : launch_timed<128, 128, 2, 2, false>(g, stream); break;

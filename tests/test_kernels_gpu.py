@@ -13,7 +13,7 @@ def _bound(A, W):
 
 @pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (1000, 64, 128), (77, 256, 96),
                                    (50, 64, 81), (33, 96, 7)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 20, 22, 25, 26])
 def test_linear_tiles(M, K, N, cfg):
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(M + K + N)
@@ -28,7 +28,7 @@ def test_linear_tiles(M, K, N, cfg):
 
 @pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (77, 256, 96), (50, 64, 81),
                                    (33, 96, 7), (515, 1152, 130)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 10, 11])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 10, 11, 20, 22, 25, 26])
 def test_linear_fp16x2(M, K, N, cfg):
     """fp16x2-split operands (hi + lo fp16, three fp16 MFMAs, fp32 accumulate): same error class as fp32."""
     from tests import hip_ops as ops
@@ -114,7 +114,7 @@ def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 20, 22, 25, 26])
 def test_conv_fp16x2(cin, cout, ks, stride, H, W, cfg):
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
