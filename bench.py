@@ -255,7 +255,9 @@ def main():
                        "matches_last_step": int(last["mconf"].numel()),
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),
-                       "model_frac_of_f32_mfma_peak": round(flops_img * total / elapsed / 1e12 / PEAK_F32_MFMA_TFLOPS / world, 4)},
+                       "model_frac_of_mfma_peak": round(flops_img * total / elapsed / 1e12 / world /
+                                                        (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0), 4),
+                       "mfma_peak_tflops_for_this_arithmetic": round(PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0, 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

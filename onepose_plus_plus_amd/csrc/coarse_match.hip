@@ -245,6 +245,91 @@ __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N,
   }
 }
 
+// Register-resident variant for L <= KMAX * 256 (L % 4 == 0): a lane keeps its confidences of the current row
+// in registers (the tie count needs no second read of the row) and a running column maximum over the wave's
+// rows; the four waves then merge their maxima with ONE LDS max per column each.
+template <int KMAX>
+__global__ __launch_bounds__(256) void conf_reg_kernel(float* __restrict__ S, int N, int L,
+                                                       const float* __restrict__ rmax, const float* __restrict__ rsum,
+                                                       const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                       float* __restrict__ row_cmax, int* __restrict__ row_arg,
+                                                       int* __restrict__ row_ties, float* __restrict__ col_part) {
+  extern __shared__ unsigned colmax_bits[];
+  const int lane = threadIdx.x & 63;
+  for (int j = threadIdx.x; j < L; j += 256) colmax_bits[j] = 0u;
+  __syncthreads();
+  float cmx[KMAX][4];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cmx[k][e] = 0.f;
+  for (int rr = 0; rr < kConfRows; ++rr) {
+    const int row = (blockIdx.x * kConfRows + rr) * 4 + (threadIdx.x >> 6);
+    if (row >= N) break;      // wave-uniform
+    float* s = S + (size_t)row * L;
+    const float rm = rmax[row], rs = rsum[row];
+    float best = -1.f;
+    int arg = 0x7fffffff;
+    float cv[KMAX][4];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int j = lane * 4 + k * 256;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cv[k][e] = -2.f;     // never equals a confidence
+      if (j < L) {
+        float v[4], cm[4], cs[4];
+        Ld<4>::load(s + j, v);
+        Ld<4>::load(cmax + j, cm);
+        Ld<4>::load(csum + j, cs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
+          const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
+          const float c = pc * pr;
+          cv[k][e] = c;
+          cmx[k][e] = fmaxf(cmx[k][e], c);
+          if (c > best) {
+            best = c;
+            arg = j + e;
+          }
+        }
+        Ld<4>::store(s + j, cv[k]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {     // wave arg-max, ties to the lowest column
+      const float ob = __shfl_xor(best, o, 64);
+      const int oa = __shfl_xor(arg, o, 64);
+      if (ob > best || (ob == best && oa < arg)) {
+        best = ob;
+        arg = oa;
+      }
+    }
+    int ties = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ties += (cv[k][e] == best) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ties += __shfl_xor(ties, o, 64);
+    if (lane == 0) {
+      row_cmax[row] = best;
+      row_arg[row] = arg;
+      row_ties[row] = ties;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int j = lane * 4 + k * 256;
+    if (j < L) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicMax(&colmax_bits[j + e], __float_as_uint(cmx[k][e]));
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < L; j += 256) col_part[(size_t)blockIdx.x * L + j] = __uint_as_float(colmax_bits[j]);
+}
+
 // ---- selection + ordered compaction: single block ------------------------------------------
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ conf, int N, int L, int wc,
                                                       const float* __restrict__ row_cmax, const int* __restrict__ row_arg,
@@ -374,7 +459,9 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   const bool fuse_cmax = (size_t)L * 4 <= 64 * 1024;
   const size_t conf_lds = fuse_cmax ? (size_t)L * 4 : 0;
   float* cpart = fuse_cmax ? part : nullptr;
-  if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  if (vec4 && fuse_cmax && L <= 16 * 256)
+    hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  else if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
   else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
   if (fuse_cmax) {
     hipLaunchKernelGGL(col_max_reduce_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, part, cblocks, L, col_cmax);

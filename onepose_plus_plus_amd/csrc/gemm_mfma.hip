@@ -898,6 +898,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 23: rc = launch_cfg<256, 128, 2, 2>(g, stream); break;     // 4 waves, 128x64 per wave
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
+    case 27: rc = launch_cfg<256, 128, 8, 2>(g, stream); break;     // 16 waves, 32x64 per wave
+    case 28: rc = launch_cfg<128, 256, 4, 4>(g, stream); break;     // 16 waves, 32x64 per wave
+    case 29: rc = launch_cfg<256, 256, 4, 4>(g, stream); break;     // 16 waves, 64x64 per wave
     case 24: rc = launch_cfg<256, 256, 2, 2>(g, stream); break;     // 4 waves, 128x128 per wave
     case 120: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<256, 128, 4, 2, true>(g, stream) : launch_timed<256, 128, 4, 2, false>(g, stream); break;
     case 121: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<128, 128, 2, 2, true>(g, stream) : launch_timed<128, 128, 2, 2, false>(g, stream); break;
