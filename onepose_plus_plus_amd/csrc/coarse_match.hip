@@ -161,11 +161,30 @@ __global__ __launch_bounds__(256) void col_max_reduce_kernel(const float* __rest
   const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
   float m = -INFINITY;
-  if (j < L)
-    for (int t = gq; t < chunks; t += 4) m = fmaxf(m, part[(size_t)t * L + j]);
+  if (j < L) {
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;   // four loads in flight per thread
+    int t = gq;
+    for (; t + 12 < chunks; t += 16) {
+      m0 = fmaxf(m0, part[(size_t)t * L + j]);
+      m1 = fmaxf(m1, part[(size_t)(t + 4) * L + j]);
+      m2 = fmaxf(m2, part[(size_t)(t + 8) * L + j]);
+      m3 = fmaxf(m3, part[(size_t)(t + 12) * L + j]);
+    }
+    for (; t < chunks; t += 4) m0 = fmaxf(m0, part[(size_t)t * L + j]);
+    m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+  }
   red[gq][c] = m;
   __syncthreads();
   if (gq == 0 && j < L) out[j] = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
+}
+
+// conf = softmax_dim1 * softmax_dim2 (coarse_matching.py:115) for one entry:
+//   exp(v - cmax)/csum * exp(v - rmax)/rsum  ==  exp((v - cmax) + (v - rmax)) * (1/csum) * (1/rsum)
+// one v_exp_f32, one v_rcp_f32 and two multiplies per entry instead of two libm exps and two IEEE divisions (the
+// sweep was VALU-bound, not HBM-bound); both exponents are <= 0, relative deviation from the two-softmax form
+// ~1e-6, far inside the 1e-4 bar.  rrs = 1 / rsum of the row.
+__device__ __forceinline__ float conf_value(float v, float cm, float cs, float rm, float rrs) {
+  return __expf((v - cm) + (v - rm)) * (__frcp_rn(cs) * rrs);
 }
 
 // ---- conf = colsoftmax * rowsoftmax, in place; per-row max / first argmax / tie count --------
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N,
     const int row = (blockIdx.x * kConfRows + rr) * 4 + (threadIdx.x >> 6);
     if (row >= N) break;      // wave-uniform
     float* s = S + (size_t)row * L;
-    const float rm = rmax[row], rs = rsum[row];
+    const float rm = rmax[row], rrs = 1.0f / rsum[row];
     float best = -1.f;
     int arg = 0x7fffffff;
     for (int j = lane * VEC; j < L; j += 64 * VEC) {
@@ -199,9 +218,7 @@ __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N,
       Ld<VEC>::load(csum + j, cs);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
-        const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
-        const float c = pc * pr;
+        const float c = conf_value(v[e], cm[e], cs[e], rm, rrs);
         v[e] = c;
         if (c > best) {
           best = c;
@@ -267,7 +284,7 @@ __global__ __launch_bounds__(256) void conf_reg_kernel(float* __restrict__ S, in
     const int row = (blockIdx.x * kConfRows + rr) * 4 + (threadIdx.x >> 6);
     if (row >= N) break;      // wave-uniform
     float* s = S + (size_t)row * L;
-    const float rm = rmax[row], rs = rsum[row];
+    const float rm = rmax[row], rrs = 1.0f / rsum[row];
     float best = -1.f;
     int arg = 0x7fffffff;
     float cv[KMAX][4];
@@ -283,9 +300,7 @@ __global__ __launch_bounds__(256) void conf_reg_kernel(float* __restrict__ S, in
         Ld<4>::load(csum + j, cs);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pc = expf(v[e] - cm[e]) / cs[e];   // softmax over the 3D points (dim 1)
-          const float pr = expf(v[e] - rm) / rs;         // softmax over the image cells (dim 2)
-          const float c = pc * pr;
+          const float c = conf_value(v[e], cm[e], cs[e], rm, rrs);
           cv[k][e] = c;
           cmx[k][e] = fmaxf(cmx[k][e], c);
           if (c > best) {
