@@ -156,6 +156,12 @@ int opp_linear(const float* A, int M, int K, const float* W, int N, int act, flo
  * into [2^14, 2^15) and is applied before the split; pass the same pointer as h2_scale to
  * opp_linear / opp_conv2d_nhwc, which multiply the accumulators by 1/s (exact). */
 int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream);
+/* C[M][N] = (residual ? residual : 0) + LayerNorm_N(A[M][K] * W[N][K]^T) * gamma + beta, N in {256, 128}:
+ * the LayerNorm (eps 1e-5) runs in the GEMM epilogue (merge -> norm1, mlp.2 -> norm2 -> +x of
+ * LoFTREncoderLayer.forward, loftr_module/transformer.py:86-94).  residual may alias C. */
+int opp_linear_layernorm(const float* A, int M, int K, const float* W, int N, const float* gamma,
+                         const float* beta, const float* residual, float* C, int h2,
+                         const float* h2_scale, void* stream);
 int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
                    float* out, int rows, int C, void* stream);
 

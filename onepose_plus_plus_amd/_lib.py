@@ -69,6 +69,8 @@ SIGNATURES = {
                                 c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "opp_linear_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p]),
     "opp_pack_h2": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "opp_image_ingest_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),

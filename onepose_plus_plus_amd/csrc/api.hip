@@ -576,11 +576,26 @@ size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, T
   return a.off;
 }
 
+struct LnArgs {   // LayerNorm fused into the GEMM epilogue (output rows = whole tile rows)
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* res = nullptr;
+  int ldres = 0;
+  float eps = 1e-5f;
+};
+
 int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit, const float* W, int M, int N, int K, float* C,
-               int act, hipStream_t s, int h2, const float* h2s) {
+               int act, hipStream_t s, int h2, const float* h2s, const LnArgs* ln = nullptr) {
   OppGemm g;
   g.h2 = h2;
   g.h2_inv = (h2 && h2s) ? h2s + 1 : nullptr;
+  if (ln) {
+    g.ln_gamma = ln->gamma;
+    g.ln_beta = ln->beta;
+    g.ln_res = ln->res;
+    g.ln_ldres = ln->ldres;
+    g.ln_eps = ln->eps;
+  }
   g.A0 = A0;
   g.lda0 = lda0;
   g.A1 = A1;
@@ -615,6 +630,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
   float* ks0 = b.ks;
   float* ks1 = b.ks + (size_t)n_seg * C;
   const float eps_attn = 1e-6f, eps_ln = 1e-5f;
+  static const int fuse_env = getenv("OPP_FUSE_LN") ? atoi(getenv("OPP_FUSE_LN")) : 1;   // tuning knob
+  const bool fuse_ln = fuse_env && (C == 256 || C == 128);
   for (size_t li = 0; li < layers.size(); ++li) {
     const EncLayerDesc& e = layers[li];
     const bool cross = is_cross[li] != 0;
@@ -652,11 +669,27 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, b.msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps_attn, s));
     OPP_TRY(opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, b.msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps_attn, s));
     }
+    if (fuse_ln) {
+      // merge -> norm1 and mlp.2 -> norm2 -> +x in the GEMM epilogues (64-row tiles spanning the whole row)
+      LnArgs n1, n2;
+      n1.gamma = e.g1;
+      n1.beta = e.b1;
+      n1.eps = eps_ln;
+      n2.gamma = e.g2;
+      n2.beta = e.b2;
+      n2.res = X;
+      n2.ldres = C;
+      n2.eps = eps_ln;
+      OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s, h2, e.smerge, &n1));   // merge + norm1 (:86-87)
+      OPP_TRY(dense_gemm(X, C, b.mrg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s, h2, e.s1));               // mlp.0 on cat([x,msg]) (:91)
+      OPP_TRY(dense_gemm(b.hid, 2 * C, nullptr, 0, 2 * C, e.w2, T, C, 2 * C, X, OPP_ACT_NONE, s, h2, e.s2, &n2));    // mlp.2 + norm2 + x (:92-94)
+    } else {
     OPP_TRY(dense_gemm(b.msg, C, nullptr, 0, C, e.wmerge, T, C, C, b.mrg, OPP_ACT_NONE, s, h2, e.smerge));  // merge (:86)
     OPP_TRY(opp_layernorm(b.mrg, C, e.g1, e.b1, nullptr, 0, b.msg, C, T, C, eps_ln, s));              // norm1 (:87)
     OPP_TRY(dense_gemm(X, C, b.msg, C, C, e.w1, T, 2 * C, 2 * C, b.hid, OPP_ACT_RELU, s, h2, e.s1));  // mlp.0 on cat([x,msg]) (:91)
     OPP_TRY(dense_gemm(b.hid, 2 * C, nullptr, 0, 2 * C, e.w2, T, C, 2 * C, b.mrg, OPP_ACT_NONE, s, h2, e.s2));  // mlp.2
     OPP_TRY(opp_layernorm(b.mrg, C, e.g2, e.b2, X, C, X, C, T, C, eps_ln, s));                        // x + norm2 (:92-94)
+    }
   }
   return OPP_OK;
 }
@@ -902,6 +935,31 @@ extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, i
   g.n_store = N;
   g.act = act;
   return opp_gemm_launch_cfg(g, tile_cfg, (hipStream_t)stream);
+}
+
+extern "C" int opp_linear_layernorm(const float* A, int M, int K, const float* W, int N, const float* gamma, const float* beta,
+                                   const float* residual, float* C, int h2, const float* h2_scale, void* stream) {
+  OPP_CHECK_ARG(A && W && gamma && beta && C, "linear_layernorm: null argument");
+  OPP_CHECK_ARG(N == 256 || N == 128, "linear_layernorm: N must be 256 or 128");
+  OppGemm g;
+  g.h2 = h2 ? 1 : 0;
+  g.h2_inv = (h2 && h2_scale) ? h2_scale + 1 : nullptr;
+  g.A0 = A;
+  g.lda0 = K;
+  g.ksplit = K;
+  g.W = W;
+  g.ldw = K;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.C = C;
+  g.ldc = N;
+  g.n_store = N;
+  g.ln_gamma = gamma;
+  g.ln_beta = beta;
+  g.ln_res = residual;
+  g.ln_ldres = N;
+  return opp_gemm_launch(g, (hipStream_t)stream);
 }
 
 extern "C" int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* out,

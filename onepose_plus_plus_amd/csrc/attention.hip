@@ -22,23 +22,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// wave64 sum on the DPP path (no LDS round trips): quad butterflies, half-row / row mirrors, then the two
-// row broadcasts leave the total in lane 63; fixed order, every lane returns the same value
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
-  return v + __int_as_float(t);
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v = dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);   // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
-  v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // ---------------------------------------------------------------------------------------
 // LayerNorm over the last dim (C = 64*VPT), one wave per row, optional residual add:
 //   out = (res ? res : 0) + (x - mean) / sqrt(var + eps) * gamma + beta
@@ -85,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < VPT; ++i) sm[r] += v[r][i];
   }
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) sm[r] = wave_sum_dpp(sm[r]);
+  for (int r = 0; r < RPW; ++r) sm[r] = opp_wave_sum_dpp(sm[r]);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) {
     mean[r] = sm[r] / (float)C;
@@ -97,7 +80,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
   }
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) sm[r] = wave_sum_dpp(sm[r]);
+  for (int r = 0; r < RPW; ++r) sm[r] = opp_wave_sum_dpp(sm[r]);
 #pragma unroll
   for (int r = 0; r < RPW; ++r) rstd[r] = 1.0f / sqrtf(sm[r] / (float)C + eps);
 #pragma unroll

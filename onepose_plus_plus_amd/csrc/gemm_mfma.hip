@@ -610,6 +610,71 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         }
       }
     }
+    if constexpr (NPASS == 1 && !kRagged && (WP == 256 || WP == 128)) {
+      if (g.ln_gamma != nullptr) {
+        // LayerNorm of the finished rows (the tile spans the row; launcher checks n_store == BN): one wave per
+        // row, four rows in lock step, same arithmetic as layernorm_kernel (attention.hip)
+        constexpr int VPT = WP / 64, NW = WAVES_M * WAVES_N, RPW = 4;
+        typedef float vec_t __attribute__((ext_vector_type(VPT)));
+        static_assert(BM % (NW * RPW) == 0 || BM / NW < RPW, "rows per wave");
+        const vec_t gmv = *reinterpret_cast<const vec_t*>(g.ln_gamma + lane * VPT);
+        const vec_t btv = *reinterpret_cast<const vec_t*>(g.ln_beta + lane * VPT);
+        constexpr int ROWS_W = BM / NW;                      // rows per wave
+        constexpr int GRP = ROWS_W < RPW ? ROWS_W : RPW;
+#pragma unroll
+        for (int r0 = 0; r0 < ROWS_W; r0 += GRP) {
+          float v[GRP][VPT], rv[GRP][VPT], sm[GRP], mean[GRP], rstd[GRP];
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) {
+            const int lr = wave * ROWS_W + r0 + r;
+            const vec_t t = *reinterpret_cast<const vec_t*>(Cs + lr * CS + lane * VPT);
+            const bool ok = m0 + lr < g.M;
+            vec_t rt;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) rt[i] = 0.f;
+            if (ok && g.ln_res) rt = *reinterpret_cast<const vec_t*>(g.ln_res + (size_t)(m0 + lr) * g.ln_ldres + lane * VPT);
+            sm[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+              v[r][i] = t[i];
+              rv[r][i] = rt[i];
+              sm[r] += t[i];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) sm[r] = opp_wave_sum_dpp(sm[r]);
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) {
+            mean[r] = sm[r] / (float)WP;
+            sm[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+              const float d = v[r][i] - mean[r];
+              sm[r] += d * d;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) sm[r] = opp_wave_sum_dpp(sm[r]);
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) rstd[r] = 1.0f / sqrtf(sm[r] / (float)WP + g.ln_eps);
+#pragma unroll
+          for (int r = 0; r < GRP; ++r) {
+            const int lr = wave * ROWS_W + r0 + r;
+            if (m0 + lr < g.M) {
+              vec_t o;
+#pragma unroll
+              for (int i = 0; i < VPT; ++i) {
+                float y = (v[r][i] - mean[r]) * rstd[r] * gmv[i] + btv[i];
+                if (g.ln_res) y = rv[r][i] + y;
+                o[i] = y;
+              }
+              *reinterpret_cast<vec_t*>(g.C + (size_t)(m0 + lr) * g.ldc + lane * VPT) = o;
+            }
+          }
+        }
+        continue;
+      }
+    }
     for (int u = tid; u < BM * (WP / 4); u += NT) {
       const int lr = u / (WP / 4);
       const int lc = (u - lr * (WP / 4)) * 4;
@@ -868,6 +933,14 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     }
   }
   OPP_CHECK_ARG(g.stat_rowmax == nullptr || cfg == 0, "gemm: fused softmax statistics need the 128x128 tile");
+  if (g.ln_gamma != nullptr) {
+    if (cfg < 0 || (cfg != 30 && cfg != 26)) cfg = g.n_store == 256 ? 30 : 26;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    OPP_CHECK_ARG(g.ln_beta && ((cfg == 30 && g.n_store == 256) || (cfg == 26 && g.n_store == 128)) && g.N == g.n_store && !g.bias &&
+                      g.act == OPP_ACT_NONE && g.res_mode == OPP_RES_NONE && g.ldc % 4 == 0 && al(g.C) && al(g.ln_gamma) &&
+                      al(g.ln_beta) && (!g.ln_res || (al(g.ln_res) && g.ln_ldres % 4 == 0)),
+                  "gemm: fused LayerNorm needs a 256- or 128-column output, no bias/activation/residual mode, aligned operands");
+  }
   const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
   bool rec = false;
   size_t slot = 0;
@@ -898,6 +971,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 23: rc = launch_cfg<256, 128, 2, 2>(g, stream); break;     // 4 waves, 128x64 per wave
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
+    case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
     case 27: rc = launch_cfg<256, 128, 8, 2>(g, stream); break;     // 16 waves, 32x64 per wave
     case 28: rc = launch_cfg<128, 256, 4, 4>(g, stream); break;     // 16 waves, 32x64 per wave
     case 29: rc = launch_cfg<256, 256, 4, 4>(g, stream); break;     // 16 waves, 64x64 per wave

@@ -94,6 +94,13 @@ struct OppGemm {
   float* stat_rowsum = nullptr;
   float* stat_colmax = nullptr;
   float* stat_colsum = nullptr;
+  // optional LayerNorm of the OUTPUT rows fused into the epilogue (tile spans the whole row: n_store == BN):
+  //   C = (ln_res ? ln_res : 0) + LN(acc) * ln_gamma + ln_beta      (transformer.py:87-88, :92-94)
+  const float* ln_gamma = nullptr;
+  const float* ln_beta = nullptr;
+  const float* ln_res = nullptr;   // row stride ln_ldres
+  int ln_ldres = 0;
+  float ln_eps = 1e-5f;
   // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
   double alg_flops = 0.0;
 };
@@ -101,3 +108,24 @@ struct OppGemm {
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream);
 // picks a tile configuration; exposed for tests / tuning (cfg < 0 = automatic)
 int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream);
+
+#ifdef __HIPCC__
+// wave64 sum on the DPP path (no LDS round trips): quad butterflies, half-row / row mirrors, then the two
+// row broadcasts leave the total in lane 63; fixed order, every lane returns the same value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float opp_dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
+__device__ __forceinline__ float opp_wave_sum_dpp(float v) {
+  v = opp_dpp_add<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+  v = opp_dpp_add<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+  v = opp_dpp_add<0x141, 0xF>(v);   // row_half_mirror
+  v = opp_dpp_add<0x140, 0xF>(v);   // row_mirror: every lane of a 16-lane row holds the row sum
+  v = opp_dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+  v = opp_dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+#endif
+

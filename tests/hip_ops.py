@@ -40,6 +40,25 @@ def linear(A, W, act=0, cfg=-1, h2=0):
     return C.cpu()
 
 
+def linear_layernorm(A, W, gamma, beta, residual=None, h2=0, in_place=False):
+    lib = _lib.load()
+    A = A.cuda().contiguous()
+    W = W.cuda().contiguous()
+    M, K = A.shape
+    N = W.shape[0]
+    sc = None
+    if h2:
+        W, sc = pack_h2(W)
+    g, b = gamma.cuda().contiguous(), beta.cuda().contiguous()
+    r = residual.cuda().contiguous() if residual is not None else None
+    C = r if (in_place and r is not None) else torch.full((M, N), float("nan"), device="cuda")
+    _lib.check(lib.opp_linear_layernorm(A.data_ptr(), M, K, W.data_ptr(), N, g.data_ptr(), b.data_ptr(),
+                                        r.data_ptr() if r is not None else None, C.data_ptr(), 1 if h2 else 0,
+                                        sc.data_ptr() if sc is not None else None, _s()), "opp_linear_layernorm")
+    torch.cuda.synchronize()
+    return C.cpu()
+
+
 def to_nhwc_padded(x_nchw, c_pad):
     b, c, h, w = x_nchw.shape
     assert b == 1

@@ -168,3 +168,24 @@ def test_layernorm(C):
     ref = F.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
     assert (ops.layer_norm(x, gam, bet) - ref.float()).abs().max() < 2e-5
     assert (ops.layer_norm(x, gam, bet, res) - (res.double() + ref).float()).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 256), (9096, 512, 256), (64, 256, 256), (77, 128, 128), (1000, 256, 128)])
+@pytest.mark.parametrize("h2", [0, 1])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_linear_layernorm_fused(M, K, N, h2, with_res):
+    """GEMM with the LayerNorm (+ residual) of LoFTREncoderLayer fused into its epilogue vs fp64."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(M + K + N + h2)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5
+    gamma = torch.rand(N, generator=g) + 0.5
+    beta = torch.randn(N, generator=g) * 0.1
+    res = torch.randn(M, N, generator=g) if with_res else None
+    y = A.double() @ W.double().T
+    ref = F.layer_norm(y, (N,), gamma.double(), beta.double(), 1e-5)
+    if with_res:
+        ref = res.double() + ref
+    got = ops.linear_layernorm(A, W, gamma, beta, res, h2=h2, in_place=with_res)
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max() < 2e-5, float((got.double() - ref).abs().max())
