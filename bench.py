@@ -39,7 +39,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF den
 _P32 = PEAK_F32_MFMA_TFLOPS
 _P16 = PEAK_F16_MFMA_TFLOPS / 3.0   # three fp16 MFMA products per algorithmic multiply-add
 SYMBOLS = {
-    "fp32": [(11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", _P32, "128, 128, 2, 2, true, 0, 4, false"),
+    "fp32": [(25, 1, "opp_gemm_kernel<128,128,4,2,conv> (fp32 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P32, "128, 128, 4, 2, true, 0, 2, false"),
+             (11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", _P32, "128, 128, 2, 2, true, 0, 4, false"),
              (1, 1, "opp_gemm_kernel<64,128,2,2,conv> (fp32 MFMA implicit-GEMM conv)", _P32, "64, 128, 2, 2, true, 0, 2, false")],
     "fp16x2": [(20, 1, "opp_gemm_kernel<256,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P16, "256, 128, 4, 2, true, 0, 2, true"),
                (25, 1, "opp_gemm_kernel<128,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv, 8 waves)", _P16, "128, 128, 4, 2, true, 0, 2, true"),

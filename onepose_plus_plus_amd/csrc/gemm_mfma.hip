@@ -920,6 +920,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
     // (fp16x2: the MFMA phase is 5x shorter, depth 2 measured best on every layer)
     if (g.conv && g.K >= 768 && cfg == 0 && !g.h2) cfg = t0 <= 512 ? 11 : 10;
+    // fp32, 128-column outputs of the 256x256-pixel layers: the 8-wave 128x128 tile (two waves per SIMD cover the
+    // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
+    if (!g.h2 && t0 >= 384 && g.n_store <= 128) cfg = 25;
     if (g.h2) {
       // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier) once they
       // still give ~a workgroup per CU; 128x256 when N > 128 so the activation split is done once per row
@@ -966,16 +969,12 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // prefetch depth experiments
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
     case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
-    case 21: rc = launch_cfg<256, 128, 4, 2, 3>(g, stream); break;
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
-    case 23: rc = launch_cfg<256, 128, 2, 2>(g, stream); break;     // 4 waves, 128x64 per wave
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
     case 27: rc = launch_cfg<256, 128, 8, 2>(g, stream); break;     // 16 waves, 32x64 per wave
     case 28: rc = launch_cfg<128, 256, 4, 4>(g, stream); break;     // 16 waves, 32x64 per wave
-    case 29: rc = launch_cfg<256, 256, 4, 4>(g, stream); break;     // 16 waves, 64x64 per wave
-    case 24: rc = launch_cfg<256, 256, 2, 2>(g, stream); break;     // 4 waves, 128x128 per wave
     case 120: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<256, 128, 4, 2, true>(g, stream) : launch_timed<256, 128, 4, 2, false>(g, stream); break;
     case 121: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<128, 128, 2, 2, true>(g, stream) : launch_timed<128, 128, 2, 2, false>(g, stream); break;
     case 191: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 91>(g, stream) : OPP_ERR_INVALID; break;   // no global loads

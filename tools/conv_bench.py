@@ -15,8 +15,8 @@ from onepose_plus_plus_amd import _lib  # noqa: E402
 
 # name, Hin, Win, cin, cout, ks, stride, cfgs
 CONVS = [
-    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 20, 21, 25, 27, 106, 107, 101, 105, 102, 103]),
-    ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11, 20, 21, 25, 27]),
+    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 20, 25, 27, 106, 107, 101, 105, 102, 103]),
+    ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11, 20, 25, 27]),
     ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 11, 10, 0, 20, 22, 25, 27, 28]),
     ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 1, 2, 0, 25, 26]),
     ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [5, 1, 2, 0, 25, 26]),
@@ -26,13 +26,13 @@ CONVS = [
 ]
 # name, M, K, N, cfgs
 DENSE = [
-    ("dense 65536x1152x128", 65536, 1152, 128, [0, 20, 21, 25, 27]),
+    ("dense 65536x1152x128", 65536, 1152, 128, [0, 20, 25, 27]),
     ("dense 65536x128x128", 65536, 128, 128, [0]),
     ("qkv 9096x256x768", 9096, 256, 768, [0, 1, 20, 22, 25, 28]),
     ("merge 9096x256x256", 9096, 256, 256, [1, 2, 0, 25, 26]),
     ("mlp1 9096x512x512", 9096, 512, 512, [0, 1, 25, 26]),
     ("mlp2 9096x512x256", 9096, 512, 256, [1, 2, 0, 25, 26]),
-    ("score 5000x256x4096", 5000, 256, 4096, [0, 20, 22, 23, 24]),
+    ("score 5000x256x4096", 5000, 256, 4096, [0, 20, 22]),
 ]
 
 
@@ -77,7 +77,7 @@ def main():
             w2 = torch.empty_like(w)
             _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack_h2")
             w = w2
-            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29)] + [-1]))
+            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
         if args.cfgs:
             cfgs = [int(c) for c in args.cfgs.split(",")]
         for cfg in cfgs:
@@ -104,7 +104,7 @@ def main():
             w2 = torch.empty_like(Wt)
             _lib.check(lib.opp_pack_h2(Wt.data_ptr(), w2.data_ptr(), Wt.numel(), None, s), "pack_h2")
             Wt = w2
-            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29)] + [-1]))
+            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
         if args.cfgs:
             cfgs = [int(c) for c in args.cfgs.split(",")]
         for cfg in cfgs:
