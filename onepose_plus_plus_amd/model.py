@@ -174,9 +174,13 @@ class OnePosePlus_model(nn.Module):
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
-        """Arithmetic of the conv / Linear GEMMs: "fp32" (fp32 MFMA) or "fp16x2" (hi/lo fp16 split,
-        three fp16 MFMAs per product, fp32 accumulate; see include/opp_hip.h opp_config.gemm_precision).
-        Not a reference option; both satisfy the 1e-4 parity bar (tests/test_e2e_gpu.py)."""
+        """Arithmetic of the conv / Linear / score GEMMs (not a reference option; every mode meets the same
+        1e-4 parity bar, tests/test_e2e_gpu.py):
+          "fp32"        exact fp32 MFMA (bit-for-bit an fmaf chain)
+          "fp16x2"      operands as hi + lo fp16 pairs, three fp16 MFMAs per product, fp32 accumulate
+                        (22-bit operand mantissas); the coarse score GEMM stays fp32
+          "fp16x2_all"  as fp16x2, score GEMM included (default; env OPP_GEMM_PRECISION overrides)
+        See include/opp_hip.h `opp_config.gemm_precision`."""
         if name not in GEMM_PRECISIONS:
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
         if name != self.gemm_precision:

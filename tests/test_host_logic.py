@@ -115,3 +115,20 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_gemm_precision_selector(monkeypatch):
+    """Host side of `opp_config.gemm_precision`: names, default, env override, pickling, bad values."""
+    import pickle
+    from onepose_plus_plus_amd import model as M
+    m = OnePosePlus_model(default_config())
+    assert m.gemm_precision == M.DEFAULT_GEMM_PRECISION == "fp16x2_all"
+    assert [m.set_gemm_precision(p)._c_config().gemm_precision for p in ("fp32", "fp16x2", "fp16x2_all")] == [0, 1, 2]
+    assert pickle.loads(pickle.dumps(m)).gemm_precision == "fp16x2_all"          # travels to Ray-style workers
+    with pytest.raises(ValueError):
+        m.set_gemm_precision("bf16")
+    monkeypatch.setenv("OPP_GEMM_PRECISION", "fp32")
+    assert OnePosePlus_model(default_config()).gemm_precision == "fp32"
+    monkeypatch.setenv("OPP_GEMM_PRECISION", "tf32")
+    with pytest.raises(ValueError):
+        OnePosePlus_model(default_config())._c_config()
