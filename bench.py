@@ -42,9 +42,9 @@ SYMBOLS = {
     "fp32": [(25, 1, "opp_gemm_kernel<128,128,4,2,conv> (fp32 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P32, "128, 128, 4, 2, true, 0, 2, false"),
              (11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", _P32, "128, 128, 2, 2, true, 0, 4, false"),
              (1, 1, "opp_gemm_kernel<64,128,2,2,conv> (fp32 MFMA implicit-GEMM conv)", _P32, "64, 128, 2, 2, true, 0, 2, false")],
-    "fp16x2": [(20, 1, "opp_gemm_kernel<256,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P16, "256, 128, 4, 2, true, 0, 2, true"),
-               (25, 1, "opp_gemm_kernel<128,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv, 8 waves)", _P16, "128, 128, 4, 2, true, 0, 2, true"),
-               (22, 1, "opp_gemm_kernel<128,256,2,4,conv,fp16x2> (3x fp16 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P16, "128, 256, 2, 4, true, 0, 2, true")],
+    "fp16x2": [(25, 1, "opp_gemm_kernel<128,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv, 8 waves)", _P16, "128, 128, 4, 2, true, 0, 2, true"),
+               (2, 1, "opp_gemm_kernel<64,64,2,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv)", _P16, "64, 64, 2, 2, true, 0, 2, true"),
+               (25, 0, "opp_gemm_kernel<128,128,4,2,dense,fp16x2> (3x fp16 MFMA GEMM, 8 waves)", _P16, "128, 128, 4, 2, false, 0, 2, true")],
 }
 
 

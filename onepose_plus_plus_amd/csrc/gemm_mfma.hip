@@ -924,14 +924,18 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
     if (!g.h2 && t0 >= 384 && g.n_store <= 128) cfg = 25;
     if (g.h2) {
-      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier) once they
-      // still give ~a workgroup per CU; 128x256 when N > 128 so the activation split is done once per row
+      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Default policy:
+      // 128x128 (73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel -- fits
+      // on the CU) wherever it still gives ~a workgroup per CU, else 64x128.  The 256x128 / 128x256 tiles
+      // (110 KB LDS) are 2-5 % faster for a kernel running alone on the two largest layers but cost 2.3 % of the
+      // throughput with three forwards in flight (no co-residency); OPP_H2_BIG_TILES=1 re-enables them,
+      // =0 falls back to the 4-wave tiles.
+      static const int big_env = getenv("OPP_H2_BIG_TILES") ? atoi(getenv("OPP_H2_BIG_TILES")) : 3;   // tuning knob
       const int t22 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 256);
       const int t20 = opp_cdiv(g.M, 256) * opp_cdiv(g.n_store, 128);
-      static const int big_env = getenv("OPP_H2_BIG_TILES") ? atoi(getenv("OPP_H2_BIG_TILES")) : 1;   // tuning knob
-      if (big_env && g.n_store > 128 && t22 >= 200) cfg = 22;
-      else if (big_env && t20 >= 200) cfg = 20;
-      else if (big_env && t0 >= 200) cfg = 25;      // 128x128 on 8 waves (32x64 per wave): the M ~ 16k layers, +11 % over 64x128
+      if (big_env == 1 && g.n_store > 128 && t22 >= 200) cfg = 22;
+      else if (big_env == 1 && t20 >= 200) cfg = 20;
+      else if (big_env && t0 >= 200) cfg = 25;      // 128x128 on 8 waves (32x64 per wave)
       else if (big_env && t1 >= 512) cfg = 26;      // 64x128 on 8 waves
     }
   }
