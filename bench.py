@@ -173,7 +173,7 @@ def main():
 
     barrier()
     if prof_in_timed:
-        _lib.check(lib.opp_profile_start(symbols[0][0], symbols[0][1], args.steps * 8), "profile_start")
+        _lib.check(lib.opp_profile_start(symbols[0][0], symbols[0][1], args.steps * 32), "profile_start")
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     barrier()
@@ -192,7 +192,7 @@ def main():
                 nsteps = args.steps
             else:
                 nsteps = min(args.steps, 40)
-                _lib.check(lib.opp_profile_start(cfg_id, conv, nsteps * 8), "profile_start")
+                _lib.check(lib.opp_profile_start(cfg_id, conv, nsteps * 32), "profile_start")
                 for i in range(nsteps):
                     step(i, 0)
                 torch.cuda.synchronize(dev)
