@@ -189,3 +189,23 @@ def test_linear_layernorm_fused(M, K, N, h2, with_res):
     got = ops.linear_layernorm(A, W, gamma, beta, res, h2=h2, in_place=with_res)
     assert torch.isfinite(got).all()
     assert (got.double() - ref).abs().max() < 2e-5, float((got.double() - ref).abs().max())
+
+
+@pytest.mark.parametrize("mag", [1e-5, 0.02, 1.0, 700.0])
+@pytest.mark.parametrize("scaled", [True, False])
+def test_pack_h2_bit_exact_vs_oracle(mag, scaled):
+    """`opp_pack_h2` (weight pre-split for the fp16x2 GEMMs): byte-exact against oracle/fp16x2_oracle.py."""
+    import numpy as np
+    from oracle import fp16x2_oracle as X
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(int(mag * 1000) + 7)
+    w = torch.randn(192, 1152, generator=g) * mag
+    w[3, 5] = 0.0
+    w[7, :8] = torch.tensor([mag * 2.0 ** -12, -mag * 2.0 ** -20, 1e-30, -1e-30, mag, -mag, mag / 3, -mag / 7])
+    out, sc = ops.pack_h2(w.cuda(), scaled=scaled)
+    torch.cuda.synchronize()
+    img, s, inv = X.split_weights(w.numpy(), scaled=scaled)
+    got = out.cpu().numpy().view(np.uint16).reshape(-1, 16)
+    assert np.array_equal(got, img)
+    if scaled:
+        assert sc.cpu().tolist() == [float(s), float(inv)]
