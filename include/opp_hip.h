@@ -51,7 +51,8 @@ typedef struct opp_config {
   /* Not a reference key: arithmetic of the conv / Linear GEMMs.  0 = fp32 MFMA (exact fp32).
    * 1 = fp16x2 split: every operand x is carried as hi = fp16(x), lo = fp16(x - hi) (22-bit mantissa),
    * three fp16 MFMAs per product (hi*lo + lo*hi + hi*hi) with fp32 accumulation, 3/16 of the fp32
-   * MFMA cycles; the coarse score GEMM stays in fp32 (its error is amplified 12.5x by the temperature).
+   * MFMA cycles (activations must stay inside the fp16 range, |x| < 65504; weights are pre-scaled per
+   * matrix and unrestricted); the coarse score GEMM stays in fp32 (its error is amplified 12.5x by the temperature).
    * 2 = as 1, and the score GEMM runs on the fp16x2 path too (image tokens split once per image). */
   int gemm_precision;
 } opp_config;
