@@ -51,8 +51,8 @@ SYMBOLS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--hw", type=int, default=512)
     ap.add_argument("--fine", action="store_true", help="full coarse-to-fine forward instead of configs[1]")
