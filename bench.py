@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Throughput bench of the 2D-3D matching forward on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,10 +13,18 @@ resident in HBM.  With N GPUs every rank owns a different synthetic object (per-
 SURVEY.md §8e): weights are broadcast once from rank 0 over RCCL, then there is no collective in
 the data path ("scaling": "weak").  Rank 0 prints ONE JSON line.
 
+Arithmetic: the module default `bf16x3` -- fp32 in / fp32 accumulate / fp32 out, GEMM operands carried
+EXACTLY as hi + mid + lo bf16 triples (24 significant bits, fp32 exponent range): not narrower than the
+reference's fp32.  `--precision fp32` runs the exact-fp32 MFMA instead; the narrower `fp16x2*` fast modes
+are reported as secondary legs only.
+
 Extra legs (rank 0, N=1 only):
-  roofline     - HIP-event timing (events recorded on the launch stream by libopp_hip.so) of
-                 every launch of the dominant kernel symbol, the 128x128-tile implicit-GEMM
-                 conv, during the timed steps; algorithmic FLOPs use unpadded channel counts.
+  roofline     - HIP-event timing (events recorded on the launch stream by libopp_hip.so) of every
+                 launch of each profiled kernel symbol: the implicit-GEMM conv / dense / score GEMM
+                 tiles (bound "mfma", algorithmic FLOPs with unpadded channel counts) and the
+                 bandwidth-bound attention gather / apply and dual-softmax passes (bound "hbm",
+                 algorithmic bytes).  The symbol with the largest time per forward is `roofline`.
+  fine_leg     - the full coarse-to-fine forward on a bank with ~1500 confident matches.
   cpu_baseline - the CPU oracle (oracle/onepose_oracle.py, a port of the reference PyTorch
                  path) timed on the host cores over a bounded sample of the same workload.
 """
@@ -24,31 +32,63 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (32x32x16)
-# GEMM kernel symbols profiled per precision: (tile cfg, conv, name, peak in ALGORITHMIC TFLOP/s).  The one with
-# the largest total time per forward is reported as `roofline`, the rest under `roofline.other_kernels`.
-_P32 = PEAK_F32_MFMA_TFLOPS
-_P16 = PEAK_F16_MFMA_TFLOPS / 3.0   # three fp16 MFMA products per algorithmic multiply-add
-SYMBOLS = {
-    "fp32": [(25, 1, "opp_gemm_kernel<128,128,4,2,conv> (fp32 MFMA implicit-GEMM 3x3 conv, 8 waves)", _P32, "128, 128, 4, 2, true, 0, 2, false"),
-             (11, 1, "opp_gemm_kernel<128,128,2,2,conv,depth4> (fp32 MFMA implicit-GEMM 3x3 conv)", _P32, "128, 128, 2, 2, true, 0, 4, false"),
-             (1, 1, "opp_gemm_kernel<64,128,2,2,conv> (fp32 MFMA implicit-GEMM conv)", _P32, "64, 128, 2, 2, true, 0, 2, false")],
-    "fp16x2": [(25, 1, "opp_gemm_kernel<128,128,4,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv, 8 waves)", _P16, "128, 128, 4, 2, true, 0, 2, true"),
-               (2, 1, "opp_gemm_kernel<64,64,2,2,conv,fp16x2> (3x fp16 MFMA implicit-GEMM conv)", _P16, "64, 64, 2, 2, true, 0, 2, true"),
-               (25, 0, "opp_gemm_kernel<128,128,4,2,dense,fp16x2> (3x fp16 MFMA GEMM, 8 waves)", _P16, "128, 128, 4, 2, false, 0, 2, true")],
-}
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# MFMA peak in ALGORITHMIC TFLOP/s per arithmetic: products issued per algorithmic multiply-add
+MFMA_PEAK = {"fp32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_F16_MFMA_TFLOPS / 6.0,
+             "fp16x2": PEAK_F16_MFMA_TFLOPS / 3.0, "fp16x2_all": PEAK_F16_MFMA_TFLOPS / 3.0}
+DTYPE = {"fp32": "f32",
+         "bf16x3": "f32 (GEMM operands carried exactly as hi+mid+lo bf16 triples, 6 bf16 MFMAs per product, fp32 accumulate)",
+         "fp16x2": "f32 (GEMM operands as hi+lo fp16 pairs [22-bit mantissa, narrower than fp32], fp32 accumulate; score GEMM fp32)",
+         "fp16x2_all": "f32 (GEMM operands as hi+lo fp16 pairs [22-bit mantissa, narrower than fp32], fp32 accumulate)"}
+PREC_ID = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 1, "bf16x3": 2}
+# candidate kernel symbols: (tile cfg, kind, template tile args, description).  kind 1 = implicit-GEMM conv,
+# 0 = dense GEMM, 2 = coarse score GEMM with the fused dual-softmax statistics.  Only symbols the model actually
+# launches for the arithmetic in use show up (launches > 0).
+GEMM_SYMBOLS = [
+    (25, 1, "128, 128, 4, 2, true", "implicit-GEMM conv, 128x128 tile, 8 waves"),
+    (26, 1, "64, 128, 2, 4, true", "implicit-GEMM conv, 64x128 tile, 8 waves"),
+    (11, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves, prefetch depth 4"),
+    (10, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves, prefetch depth 3"),
+    (0, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves"),
+    (1, 1, "64, 128, 2, 2, true", "implicit-GEMM conv, 64x128 tile, 4 waves"),
+    (2, 1, "64, 64, 2, 2, true", "implicit-GEMM conv, 64x64 tile, 4 waves"),
+    (25, 0, "128, 128, 4, 2, false", "dense GEMM (QKV, mlp.0, stem), 128x128 tile, 8 waves"),
+    (0, 0, "128, 128, 2, 2, false", "dense GEMM (QKV, mlp.0, stem), 128x128 tile, 4 waves"),
+    (26, 0, "64, 128, 2, 4, false", "dense GEMM, 64x128 tile, 8 waves"),
+    (1, 0, "64, 128, 2, 2, false", "dense GEMM, 64x128 tile, 4 waves"),
+    (2, 0, "64, 64, 2, 2, false", "dense GEMM, 64x64 tile, 4 waves"),
+    (30, 0, "64, 256, 2, 4, false", "dense GEMM + fused LayerNorm (merge, mlp.2), 64x256 tile, 8 waves"),
+    (25, 2, "128, 128, 4, 2, false", "coarse score GEMM + fused dual-softmax statistics, 128x128 tile, 8 waves"),
+    (0, 2, "128, 128, 2, 2, false", "coarse score GEMM + fused dual-softmax statistics, 128x128 tile, 4 waves"),
+]
+DEPTH_OF_CFG = {10: 3, 11: 4}
+HBM_SYMBOLS = [
+    (1000, "linattn_kv_mfma_kernel", "linear-attention gather: sum_s phi(K_s)^T V_s (K, V read once + chunk partials written)"),
+    (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
+    (1002, "conf_reg_kernel", "dual-softmax product over the N x L score matrix (read + written once)"),
+]
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=150)
@@ -59,14 +99,30 @@ def main():
     ap.add_argument("--thr", type=float, default=0.1)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the short exact-fp32 GEMM comparison run")
-    ap.add_argument("--precision", default=None, choices=["fp32", "fp16x2", "fp16x2_all"],
-                    help="GEMM arithmetic (default: the module default / OPP_GEMM_PRECISION)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other-arithmetic and fine-stage legs")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "fp16x2", "fp16x2_all"],
+                    help="GEMM arithmetic (default: the module default bf16x3 / OPP_GEMM_PRECISION)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "3")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
-                         "2 Ray workers per GPU, inference_OnePosePlus.py:18-26); steps are split evenly")
-    args = ap.parse_args()
+                         "2 Ray workers per GPU, inference_OnePosePlus.py:18-26)")
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU over RCCL, the same command
+        # line the driver uses (src/inference.py:83-106 fans objects out to GPUs the same way, with Ray)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
+    run(args)
+
+
+def run(args):
+    import torch
     from onepose_plus_plus_amd import OnePosePlus_model, default_config, _lib
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
 
@@ -74,13 +130,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL
+    if "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -92,7 +148,6 @@ def main():
     if args.precision:
         model.set_gemm_precision(args.precision)
     precision = model.gemm_precision
-    symbols = SYMBOLS["fp32" if precision == "fp32" else "fp16x2"]
     sd = make_state_dict(cfg, 0) if rank == 0 else None
     model = model.to(dev)
     if dist is not None:
@@ -120,145 +175,125 @@ def main():
     bank = {k: datas[0][k] for k in ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
     for d in datas:
         d.update(bank)          # the bank is per-object constant: one resident copy
+    torch.cuda.synchronize(dev)
 
-    def step(i, slot=0):
-        d = dict(datas[i % n_img])
+    def step(i, slot=0, pool=None, mods=None):
+        pool = pool or datas
+        d = dict(pool[i % len(pool)])
         with torch.no_grad():
             if streams[slot] is None:
-                models[slot](d)
+                (mods or models)[slot](d)
             else:
                 with torch.cuda.stream(streams[slot]):
-                    models[slot](d)
+                    (mods or models)[slot](d)
         return d
 
-    def run_steps(n):
-        """n forwards; with several streams one host thread per stream keeps its forward in flight
-        (the forward's single D2H sync of the match count releases the GIL)."""
+    def run_steps(n, pool=None, mods=None):
+        """EXACTLY n forwards.  With several streams one host thread per stream keeps its forward in flight (the
+        forward's single D2H sync of the match count releases the GIL); the threads draw step indices from one
+        shared counter, so no stream idles while another still has a backlog."""
         if n_streams == 1:
             last = None
             for i in range(n):
-                last = step(i)
+                last = step(i, 0, pool, mods)
             return last
-        import threading
         out = [None] * n_streams
+        nxt = [0]
+        lock = threading.Lock()
 
         def worker(slot):
             torch.cuda.set_device(dev)
-            for i in range(n // n_streams + (1 if slot < n % n_streams else 0)):     # exactly n forwards in total
-                out[slot] = step(i * n_streams + slot, slot)
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= n:
+                    break
+                out[slot] = step(i, slot, pool, mods)
             streams[slot].synchronize()
         th = [threading.Thread(target=worker, args=(k,)) for k in range(n_streams)]
         for t in th:
             t.start()
         for t in th:
             t.join()
-        return out[0]
+        return next(o for o in out if o is not None)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # warm-up: W untimed steps on EVERY stream (packs the weights, sizes the workspaces, fills the per-object token
+    # cache), then one concurrent round so that the streams, their host threads and the clocks are in steady state
     for i in range(args.warmup):
         for k in range(n_streams):
             step(i, k)
+    torch.cuda.synchronize(dev)
+    if n_streams > 1:
+        run_steps(2 * n_streams)
     lib = _lib.load()
     prof = (not args.no_roofline) and rank == 0 and world == 1
-    prof_in_timed = prof and n_streams == 1
-
-    def prof_stop():
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "profile_stop")
-        return ms.value, fl.value, n.value
 
     barrier()
-    if prof_in_timed:
-        _lib.check(lib.opp_profile_start(symbols[0][0], symbols[0][1], args.steps * 32), "profile_start")
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    roof = None
-    if prof:
-        # HIP events recorded by the library on the launch stream around every launch of one kernel symbol.
-        # With several forwards in flight kernels of different streams share the CUs, so a kernel's own launch
-        # duration is only meaningful on its own: the symbols are then timed in single-stream passes of the
-        # same steps right after the timed region (`measured` says which).
-        meas = []
-        for si, (cfg_id, conv, name, peak, tmpl) in enumerate(symbols):
-            if si == 0 and prof_in_timed:
-                ms, fl, n = prof_stop()
-                how = "timed region"
-                nsteps = args.steps
-            else:
-                nsteps = min(args.steps, 40)
-                _lib.check(lib.opp_profile_start(cfg_id, conv, nsteps * 32), "profile_start")
-                for i in range(nsteps):
-                    step(i, 0)
-                torch.cuda.synchronize(dev)
-                ms, fl, n = prof_stop()
-                how = "single-stream pass of %d steps after the timed region" % nsteps
-            if n > 0 and ms > 0:
-                ach = fl / (ms * 1e-3) / 1e12
-                meas.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                             "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "symbol": tmpl,
-                             "measured": "HIP events on the launch stream, " + how,
-                             "launches": n, "launches_per_step": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
-                             "us_per_step": round(ms * 1e3 / nsteps, 1), "alg_gflop_per_launch": round(fl / n / 1e9, 3)})
-        if meas:
-            meas.sort(key=lambda m: -m["us_per_step"])
-            roof = meas[0]
-            tpath = os.path.join(ROOT, "profiles", "traffic_gemm_symbols_%s.json" % ("fp32" if precision == "fp32" else "fp16x2"))
-            if os.path.exists(tpath):     # HBM bytes per launch from the committed rocprofv3 --pmc passes
-                with open(tpath) as f:
-                    tr = json.load(f)
-                for m in meas:
-                    m["traffic"] = tr.get(m["symbol"])
-            roof["other_kernels"] = meas[1:]
+    matches_last = int(last["mconf"].numel())
+
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        devs = [None] * world
+        props = torch.cuda.get_device_properties(dev)
+        dist.all_gather_object(devs, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                                      "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()})
+        n_ranks_seen = dist.get_world_size()
+    else:
+        props = torch.cuda.get_device_properties(dev)
+        devs = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+                 "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}]
+        n_ranks_seen = 1
 
-    fp32_leg = None
-    if rank == 0 and world == 1 and precision != "fp32" and not args.no_fp32_leg:
-        # the same forwards with the exact-fp32 MFMA GEMMs, for reference beside the headline value
-        for m in models:
-            m.set_gemm_precision("fp32").to(dev)
-        for k in range(n_streams):
-            step(0, k)
-        torch.cuda.synchronize(dev)
-        n32 = min(args.steps, 30)
-        t1 = time.perf_counter()
-        run_steps(n32)
-        torch.cuda.synchronize(dev)
-        fp32_leg = {"value": round(n32 / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n32,
-                    "gemm_precision": "fp32"}
+    roof = None
+    if prof:
+        roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps, 20))
+
+    legs = {}
+    if rank == 0 and world == 1 and not args.no_legs:
+        legs = other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, args, lib, _lib)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(cfg, make_state_dict(cfg, 0), args, make_inputs)
+        cpu = cpu_baseline(torch, cfg, make_state_dict(cfg, 0), args, make_inputs)
 
     if rank == 0:
         total = args.steps * world
         flops_img = 2 * (126.726e9 + 6 * (4096 + args.n_points) * 671744 + args.n_points * 4096 * 256)
+        peak = MFMA_PEAK[precision]
         out = {
             "metric": "query images/sec (2D-3D match fwd) at 512x512 img x 5k pts",
             "value": round(total / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if precision == "fp32" else "f32 (GEMM operands as hi+lo fp16 pairs, fp32 accumulate)",
+            "dtype": DTYPE[precision],
             "data": "synthetic (seeded random image, descriptor bank and weights)",
             "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
-                                   "%d forward(s) in flight per GPU, one object per GPU"
-                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams),
-                       "streams_per_gpu": n_streams, "gemm_precision": precision, "fp32_gemm_leg": fp32_leg,
-                       "matches_last_step": int(last["mconf"].numel()),
+                                   "%d forward(s) in flight per GPU on separate HIP streams, one object per GPU; image and "
+                                   "descriptor banks resident in HBM; the image-independent 3D-point tokens (keypoint-MLP "
+                                   "encoding of the bank, <0.1 %% of the FLOPs) are cached per object; thr %.2f gives M = %d "
+                                   "matches on these random weights (the conf matrix is still fully materialised)"
+                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams,
+                                      args.thr, matches_last),
+                       "streams_per_gpu": n_streams, "gemm_precision": precision,
+                       "matches_last_step": matches_last, "object_token_cache": True,
+                       "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),
-                       "model_frac_of_mfma_peak": round(flops_img * total / elapsed / 1e12 / world /
-                                                        (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0), 4),
-                       "mfma_peak_tflops_for_this_arithmetic": round(PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0, 1)},
+                       "model_frac_of_mfma_peak": round(flops_img * total / elapsed / 1e12 / world / peak, 4),
+                       "mfma_peak_tflops_for_this_arithmetic": round(peak, 1),
+                       **legs},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
@@ -266,7 +301,144 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, sd, args, make_inputs):
+def prof_run(lib, _lib, torch, dev, step, tile_cfg, kind, nsteps, pool=None, mods=None):
+    """one single-stream pass of `nsteps` forwards with one kernel symbol armed -> (ms, work, launches)"""
+    _lib.check(lib.opp_profile_start(tile_cfg, kind, nsteps * 40), "profile_start")
+    for i in range(nsteps):
+        step(i, 0, pool, mods)
+    torch.cuda.synchronize(dev)
+    ms, wk, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(wk), ctypes.byref(n)), "profile_stop")
+    return ms.value, wk.value, n.value
+
+
+def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
+    """HIP events recorded by the library on the launch stream around every launch of one kernel symbol.  With
+    several forwards in flight kernels of different streams share the CUs, so a kernel's own launch duration is only
+    meaningful on its own: every symbol is timed in a single-stream pass of the same steps right after the timed
+    region."""
+    how = "HIP events on the launch stream, single-stream pass of %d steps after the timed region" % nsteps
+    pid = PREC_ID[precision]
+    peak = MFMA_PEAK[precision]
+    tpath = os.path.join(ROOT, "profiles", "traffic_symbols_%s.json" % precision)
+    traffic = {}
+    if os.path.exists(tpath):     # HBM bytes per launch from the committed rocprofv3 --pmc passes
+        with open(tpath) as f:
+            traffic = json.load(f)
+    meas = []
+    for cfg_id, kind, tile, what in GEMM_SYMBOLS:
+        spid = 0 if (kind == 2 and precision == "fp16x2") else pid      # fp16x2: the score GEMM stays fp32
+        ms, fl, n = prof_run(lib, _lib, torch, dev, step, cfg_id, kind, nsteps)
+        if n <= 0 or ms <= 0:
+            continue
+        speak = MFMA_PEAK["fp32"] if spid == 0 else peak
+        sym = "%s, 0, %d, %d" % (tile, DEPTH_OF_CFG.get(cfg_id, 2), spid)
+        ach = fl / (ms * 1e-3) / 1e12
+        meas.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(speak, 1), "unit": "TFLOP/s",
+                     "frac": round(ach / speak, 4), "traffic": traffic.get(sym),
+                     "kernel": "opp_gemm_kernel<%s> (%s, %s operands)" % (sym, what, ["fp32", "fp16x2", "bf16x3"][spid]),
+                     "symbol": sym, "measured": how, "launches": n, "launches_per_step": round(n / nsteps, 2),
+                     "avg_launch_us": round(ms * 1e3 / n, 2), "us_per_step": round(ms * 1e3 / nsteps, 1),
+                     "alg_gflop_per_launch": round(fl / n / 1e9, 3)})
+    for sid, kname, what in HBM_SYMBOLS:
+        ms, by, n = prof_run(lib, _lib, torch, dev, step, sid, 0, nsteps)
+        if n <= 0 or ms <= 0:
+            continue
+        ach = by / (ms * 1e-3) / 1e9
+        meas.append({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic.get(kname),
+                     "kernel": "%s (%s)" % (kname, what), "symbol": kname, "measured": how, "launches": n,
+                     "launches_per_step": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
+                     "us_per_step": round(ms * 1e3 / nsteps, 1), "alg_mbytes_per_launch": round(by / n / 1e6, 3)})
+    if not meas:
+        return None
+    meas.sort(key=lambda m: -m["us_per_step"])
+    roof = meas[0]
+    roof["other_kernels"] = meas[1:]
+    return roof
+
+
+def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, args, lib, _lib):
+    """Secondary measurements of the same run: the other GEMM arithmetics on the same workload, and the full
+    coarse-to-fine forward on a bank with ~1500 confident matches (fine stage timed with HIP events)."""
+    legs = {}
+    other = {}
+    for p in ("fp32", "fp16x2_all"):
+        if p == precision:
+            continue
+        for m in models:
+            m.set_gemm_precision(p).to(dev)
+        for k in range(n_streams):
+            step(0, k)
+        torch.cuda.synchronize(dev)
+        n = min(args.steps, 30)
+        t1 = time.perf_counter()
+        run_steps(n)
+        torch.cuda.synchronize(dev)
+        other[p] = {"value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
+                    "note": "exact fp32 MFMA GEMMs" if p == "fp32" else
+                            "opt-in fast mode, operands NARROWER than fp32 (22-bit mantissa, fp16 range): not the headline"}
+    for m in models:
+        m.set_gemm_precision(precision).to(dev)
+    legs["other_arithmetics"] = other
+    try:
+        legs["fine_leg"] = fine_leg(torch, dev, precision, lib, _lib)
+    except Exception as e:      # the fixture is optional for the headline
+        legs["fine_leg"] = {"error": str(e)}
+    return legs
+
+
+def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):
+    """Full coarse-to-fine forward (BASELINE configs[2] shape) on the committed high-confidence bank
+    (tests/golden/highconf_512x512_n3000.npz: ~1500 matches): whole-forward rate and the fine stage on its own."""
+    import numpy as np
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    from tests.golden.cases import HIGHCONF_CASES
+    name = "highconf_512x512_n3000"
+    hw, n, n_planted, thr, wseed, iseed = HIGHCONF_CASES[name]
+    cfg = default_config(thr=thr)
+    model = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).to(dev)
+    model.load_state_dict(make_state_dict(cfg, wseed), strict=True)
+    data = make_inputs(n, hw, iseed)
+    data["descriptors3d_coarse_db"] = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["bank_c_f16"]).float()
+    data = {k: v.to(dev) for k, v in data.items()}
+
+    def fwd():
+        d = dict(data)
+        with torch.no_grad():
+            model(d)
+        return d
+    for _ in range(3):
+        d = fwd()
+    torch.cuda.synchronize(dev)
+    M = int(d["mconf"].numel())
+    t = time.perf_counter()
+    for _ in range(nsteps):
+        fwd()
+    torch.cuda.synchronize(dev)
+    full_ms = (time.perf_counter() - t) / nsteps * 1e3
+    _lib.check(lib.opp_profile_start(1003, 0, nsteps * 40), "profile_start")
+    for _ in range(nsteps):
+        fwd()
+    torch.cuda.synchronize(dev)
+    ms, by, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(by), ctypes.byref(nl)), "profile_stop")
+    out = {"workload": "full coarse-to-fine forward, %dx%d x %d points, thr %.1f, bank optimised for confident matches "
+                       "(tests/golden/%s.npz), single stream" % (hw[0], hw[1], n, thr, name),
+           "matches": M, "ms_per_forward": round(full_ms, 3), "images_per_s": round(1e3 / full_ms, 2)}
+    if nl.value > 0 and ms.value > 0:
+        fine_ms = ms.value / nsteps
+        gather_bytes = M * 25 * 128 * 4.0
+        out.update({"fine_stage_ms": round(fine_ms, 4), "fine_stage_launches_per_forward": round(nl.value / nsteps, 1),
+                    "fine_ms_per_1000_matches": round(fine_ms / max(M, 1) * 1000, 4),
+                    "window_gather_mbytes": round(gather_bytes / 1e6, 2),
+                    "fine_stage_alg_gbs": round(by.value / nsteps / (fine_ms * 1e-3) / 1e9, 1),
+                    "fine_stage_frac_of_hbm_peak": round(by.value / nsteps / (fine_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+    return out
+
+
+def cpu_baseline(torch, cfg, sd, args, make_inputs):
     """Oracle (port of the reference PyTorch CPU path) timed on the host cores over a bounded
     sample: forwards of the SAME workload for ~cpu_seconds.  The thread count is picked by a
     short calibration (a 256-thread pool on this class of box is slower than a small one), and

@@ -48,11 +48,17 @@ typedef struct opp_config {
   float match_thr;         /* coarse_matching.thr */
   int match_border_rm;     /* coarse_matching.border_rm */
   float match_temperature; /* coarse_matching.dual_softmax.temperature */
-  /* Not a reference key: arithmetic of the conv / Linear GEMMs.  0 = fp32 MFMA (exact fp32).
-   * 1 = fp16x2 split: every operand x is carried as hi = fp16(x), lo = fp16(x - hi) (22-bit mantissa),
-   * three fp16 MFMAs per product (hi*lo + lo*hi + hi*hi) with fp32 accumulation, 3/16 of the fp32
-   * MFMA cycles (activations must stay inside the fp16 range, |x| < 65504; weights are pre-scaled per
-   * matrix and unrestricted); the coarse score GEMM stays in fp32 (its error is amplified 12.5x by the temperature).
+  /* Not a reference key: arithmetic of the conv / Linear / score GEMMs (fp32 in, fp32 accumulate, fp32 out in
+   * every mode).
+   * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain).
+   * 3 = bf16x3 split (the module default): every operand x is carried EXACTLY as hi + mid + lo bf16
+   *     (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 significant bits, fp32 exponent range, no
+   *     range restriction), six bf16 MFMAs per product (the dropped mid*lo, lo*mid, lo*lo terms are <= 2^-26 |a||b|,
+   *     below fp32's own rounding), 6/16 of the fp32 MFMA cycles.  Not narrower than fp32.
+   * 1 = fp16x2 split (opt-in fast mode, NARROWER than fp32): x ~ hi + lo fp16 (22-bit mantissa), three fp16 MFMAs
+   *     per product, 3/16 of the fp32 MFMA cycles.  Activations must stay inside the fp16 range (|x| < 65504;
+   *     the kernels flag non-finite outputs, see opp_forward_coarse `count[1]`), values below 2^-3 keep an
+   *     absolute 2^-25 error; weights are pre-scaled per matrix and unrestricted.  The coarse score GEMM stays fp32.
    * 2 = as 1, and the score GEMM runs on the fp16x2 path too (image tokens split once per image). */
   int gemm_precision;
 } opp_config;
@@ -69,6 +75,11 @@ int opp_version(void);
  * returns the state-dict key expected at index i. */
 int opp_create(const opp_config* cfg, opp_ctx** out);
 void opp_destroy(opp_ctx* ctx);
+/* fp16x2 range guard (gemm_precision 1 / 2 only; a no-op otherwise): `flag` is a device int that every stage
+ * enqueued through this ctx ORs with 1 when an fp16x2 GEMM produced a non-finite value, i.e. an activation left the
+ * fp16 range (|x| >~ 1.3e5) -- or the input itself was not finite.  The caller zeroes it, reads it after the
+ * stream work completed, and re-runs in another arithmetic (the Python module switches to bf16x3).  NULL disables. */
+int opp_set_status_flag(opp_ctx* ctx, int* flag);
 int opp_num_weights(const opp_ctx* ctx);
 const char* opp_weight_name(const opp_ctx* ctx, int i);
 long long opp_weight_numel(const opp_ctx* ctx, int i);
@@ -140,28 +151,32 @@ int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* ban
  * [cout_pad][ks*ks*cin_pad] (from opp_pack_conv_weight); bias [cout_pad] or NULL; residual:
  * res_mode 0 none, 1 same-shape NHWC [Hout][Wout][cout_pad], 2 bilinear x2 (align_corners)
  * upsample of NHWC [Hout/2][Wout/2][cout_pad]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
- * tile_cfg < 0 selects automatically.  h2 = 1: w_packed was additionally pre-split (opp_pack_h2);
- * h2_scale = the scale2 pointer given to opp_pack_h2, or NULL. */
+ * tile_cfg < 0 selects automatically.  prec = operand arithmetic: 0 fp32; 1 fp16x2 (w_packed additionally
+ * pre-split by opp_pack_h2, h2_scale = the scale2 pointer given to it, or NULL); 2 bf16x3 (w_packed pre-split by
+ * opp_pack_b3, 1.5x the floats). */
 int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed,
                     const float* bias, int cout_pad, int ks, int stride, const float* residual,
-                    int res_mode, int act, float* y, int tile_cfg, int h2, const float* h2_scale,
+                    int res_mode, int act, float* y, int tile_cfg, int prec, const float* h2_scale,
                     void* stream);
 int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks,
                          int cout_pad, int cin_pad, float* out, void* stream);
-/* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  h2 = 1: W was pre-split by
- * opp_pack_h2 and the fp16x2 kernel is used (tile_cfg 0, 1, 2, 10, 11 or < 0). */
+/* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  prec as above (1: W pre-split by opp_pack_h2,
+ * 2: by opp_pack_b3). */
 int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,
-               int tile_cfg, int h2, const float* h2_scale, void* stream);
+               int tile_cfg, int prec, const float* h2_scale, void* stream);
 /* fp16x2 pre-split of a K-contiguous weight matrix (n floats, n % 8 == 0, out != in, same size).
  * scale2 (device, 2 floats, may be NULL): receives {s, 1/s}, s the power of two that brings max|w|
  * into [2^14, 2^15) and is applied before the split; pass the same pointer as h2_scale to
  * opp_linear / opp_conv2d_nhwc, which multiply the accumulators by 1/s (exact). */
 int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream);
+/* bf16x3 pre-split of a K-contiguous operand (n floats, n % 8 == 0, out != in): out receives 1.5 n floats, every
+ * 8 consecutive values as 48 bytes [hi x8 | mid x8 | lo x8] bf16 with hi + mid + lo == x exactly. */
+int opp_pack_b3(const float* in, float* out, size_t n, void* stream);
 /* C[M][N] = (residual ? residual : 0) + LayerNorm_N(A[M][K] * W[N][K]^T) * gamma + beta, N in {256, 128}:
  * the LayerNorm (eps 1e-5) runs in the GEMM epilogue (merge -> norm1, mlp.2 -> norm2 -> +x of
  * LoFTREncoderLayer.forward, loftr_module/transformer.py:86-94).  residual may alias C. */
 int opp_linear_layernorm(const float* A, int M, int K, const float* W, int N, const float* gamma,
-                         const float* beta, const float* residual, float* C, int h2,
+                         const float* beta, const float* residual, float* C, int prec,
                          const float* h2_scale, void* stream);
 int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual,
                    float* out, int rows, int C, void* stream);
@@ -187,8 +202,9 @@ int opp_pnp_ransac(const float* pts2d, const float* pts3d, int n_points, const d
                    int refine_iters, double* pose_out, int* inlier_mask, int* n_inliers, int* ok,
                    void* workspace, size_t workspace_bytes, void* stream);
 
-/* Tuning aid: device buffer (4 x uint64 per wave) for the phase time stamps written by the timed conv
- * variants (tile_cfg 120 = 256x128 / 8 waves, 121 = 128x128 / 4 waves); NULL disables. */
+/* Tuning aid (libraries built with -DOPP_TUNING only; otherwise returns an error): device buffer (4 x uint64 per
+ * wave) for the phase time stamps written by the timed conv variants (tile_cfg 120 = 256x128 / 8 waves,
+ * 121 = 128x128 / 4 waves, 122 = 128x128 / 8 waves); NULL disables. */
 int opp_debug_timestamps(void* buf);
 
 /* ---- live kernel timing for bench.py's roofline leg ---------------------------------------

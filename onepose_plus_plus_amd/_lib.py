@@ -8,7 +8,8 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libopp_hip.so")
+# OPP_HIP_LIB: explicit path of another build of the same library (tools/ use the -DOPP_TUNING one)
+LIB_PATH = os.environ.get("OPP_HIP_LIB") or os.path.join(_HERE, "libopp_hip.so")
 OPP_MAX_LAYERS = 16
 
 
@@ -42,6 +43,7 @@ SIGNATURES = {
     "opp_version": (c_int, []),
     "opp_create": (c_int, [POINTER(OppConfig), POINTER(c_void_p)]),
     "opp_destroy": (None, [c_void_p]),
+    "opp_set_status_flag": (c_int, [c_void_p, c_void_p]),
     "opp_num_weights": (c_int, [c_void_p]),
     "opp_weight_name": (c_char_p, [c_void_p, c_int]),
     "opp_weight_numel": (c_longlong, [c_void_p, c_int]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "opp_linear_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p]),
     "opp_pack_h2": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "opp_pack_b3": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "opp_image_ingest_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "opp_debug_timestamps": (c_int, [c_void_p]),

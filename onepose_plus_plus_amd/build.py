@@ -1,6 +1,9 @@
 """Builds libopp_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-    python -m onepose_plus_plus_amd.build [--force]
+    python -m onepose_plus_plus_amd.build [--force] [--tuning]
+
+`--tuning` builds libopp_hip_tuning.so with -DOPP_TUNING (phase-stamped / ablated kernel variants and the
+environment knobs used by tools/; never loaded by the product path -- point OPP_HIP_LIB at it explicitly).
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the
 resulting .so travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
@@ -14,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_build")
 LIB = os.path.join(HERE, "libopp_hip.so")
-SOURCES = ["gemm_mfma.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "api.hip"]
+SOURCES = ["gemm_mfma.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -33,7 +36,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
+    global OBJ, LIB
+    obj_dir = OBJ + ("_tuning" if tuning else "")
+    lib_path = LIB.replace(".so", "_tuning.so") if tuning else LIB
+    flags = FLAGS + (["-DOPP_TUNING"] if tuning else [])
+    return _build(force, verbose, obj_dir, lib_path, flags)
+
+
+def _build(force, verbose, OBJ, LIB, FLAGS):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -67,4 +78,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))

@@ -30,6 +30,16 @@ namespace {
 
 inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
+// opp_config.gemm_precision -> OPP_PREC_* of the conv / Linear GEMMs and of the coarse score GEMM
+inline int gemm_prec(const opp_config& cfg) {
+  return cfg.gemm_precision == 3 ? OPP_PREC_BF16X3 : cfg.gemm_precision ? OPP_PREC_FP16X2 : OPP_PREC_FP32;
+}
+inline int score_prec(const opp_config& cfg) {
+  return cfg.gemm_precision == 3 ? OPP_PREC_BF16X3 : cfg.gemm_precision == 2 ? OPP_PREC_FP16X2 : OPP_PREC_FP32;
+}
+// floats occupied by a K-contiguous operand of n values once pre-split for `prec` (bf16x3: 48 B per 8 values)
+inline size_t split_floats(size_t n, int prec) { return prec == OPP_PREC_BF16X3 ? n / 2 * 3 : n; }
+
 struct WeightEntry {
   std::string name;
   long long numel;
@@ -76,11 +86,21 @@ struct opp_ctx {
   std::vector<EncLayerDesc> coarse, fine;
   bool packed = false;
   size_t packed_bytes = 0;
+  int* status_flag = nullptr;      // opp_set_status_flag
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
-  float* scratch_h2 = nullptr;     // fp16x2 pre-split staging (largest weight matrix)
+  float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
 };
 
 namespace {
+
+// fp16x2 range guard: the status flag of the ctx whose stage this host thread is enqueuing (every OppGemm
+// built below picks it up)
+thread_local int* t_status_flag = nullptr;
+struct FlagScope {
+  int* prev;
+  explicit FlagScope(const opp_ctx* c) : prev(t_status_flag) { t_status_flag = c ? c->status_flag : nullptr; }
+  ~FlagScope() { t_status_flag = prev; }
+};
 
 int add_w(opp_ctx* c, const std::string& name, long long numel) {
   c->table.push_back({name, numel});
@@ -203,6 +223,11 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
 }
 
 extern "C" void opp_destroy(opp_ctx* ctx) { delete ctx; }
+extern "C" int opp_set_status_flag(opp_ctx* ctx, int* flag) {
+  OPP_CHECK_ARG(ctx, "set_status_flag: null ctx");
+  ctx->status_flag = flag;
+  return OPP_OK;
+}
 extern "C" int opp_num_weights(const opp_ctx* ctx) { return ctx ? (int)ctx->table.size() : 0; }
 extern "C" const char* opp_weight_name(const opp_ctx* ctx, int i) {
   return (ctx && i >= 0 && i < (int)ctx->table.size()) ? ctx->table[i].name.c_str() : nullptr;
@@ -237,15 +262,17 @@ size_t plan_pack(opp_ctx* c, void* base) {
     const size_t dc = c->cfg.coarse_d_model, df = c->cfg.fine_d_model;
     mx = 4 * dc * dc > mx ? 4 * dc * dc : mx;
     mx = 4 * df * df > mx ? 4 * df * df : mx;
-    c->scratch_h2 = c->cfg.gemm_precision ? a.f(mx) : nullptr;
+    c->scratch_h2 = c->cfg.gemm_precision ? a.f(split_floats(mx, gemm_prec(c->cfg))) : nullptr;
   }
-  const bool h2 = c->cfg.gemm_precision != 0;
-  c->stem.w = a.f((size_t)c->stem.cout * 64);
+  const int prec = gemm_prec(c->cfg);
+  const bool h2 = prec == OPP_PREC_FP16X2;   // per-matrix power-of-two scales exist for fp16x2 only
+  auto wf = [&](size_t n) { return a.f(split_floats(n, prec)); };
+  c->stem.w = wf((size_t)c->stem.cout * 64);
   c->stem.bias = a.f(pad32(c->stem.cout));
   c->stem.h2s = h2 ? a.f(2) : nullptr;
   for (ConvDesc* d : all_convs(c)) {
     d->h2s = h2 ? a.f(2) : nullptr;
-    d->w = a.f(d->w_floats());
+    d->w = wf(d->w_floats());
     d->bias = d->bn_idx >= 0 ? a.f(d->cout_pad()) : nullptr;
   }
   if (c->cfg.kpt_enc_enable) {
@@ -257,10 +284,10 @@ size_t plan_pack(opp_ctx* c, void* base) {
   }
   auto plan_tr = [&](std::vector<EncLayerDesc>& L, int d) {
     for (auto& e : L) {
-      e.wqkv = a.f((size_t)3 * d * d);
-      e.wmerge = a.f((size_t)d * d);
-      e.w1 = a.f((size_t)4 * d * d);
-      e.w2 = a.f((size_t)2 * d * d);
+      e.wqkv = wf((size_t)3 * d * d);
+      e.wmerge = wf((size_t)d * d);
+      e.w1 = wf((size_t)4 * d * d);
+      e.w2 = wf((size_t)2 * d * d);
       e.sqkv = h2 ? a.f(2) : nullptr;
       e.smerge = h2 ? a.f(2) : nullptr;
       e.s1 = h2 ? a.f(2) : nullptr;
@@ -342,10 +369,12 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
   };
   OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
   OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
-  if (c->cfg.gemm_precision) {   // pre-split every GEMM weight matrix into fp16 hi/lo halves (same footprint)
+  if (c->cfg.gemm_precision) {   // pre-split every GEMM weight matrix: fp16 hi/lo (same footprint) or bf16 hi/mid/lo (1.5x)
+    const int prec = gemm_prec(c->cfg);
     auto split = [&](float* wm, size_t n, float* sc) -> int {
-      OPP_TRY(opp_h2_split(wm, c->scratch_h2, n, sc, s));
-      return copy_f(wm, c->scratch_h2, n, s);
+      if (prec == OPP_PREC_BF16X3) OPP_TRY(opp_b3_split(wm, c->scratch_h2, n, s));
+      else OPP_TRY(opp_h2_split(wm, c->scratch_h2, n, sc, s));
+      return copy_f(wm, c->scratch_h2, split_floats(n, prec), s);
     };
     OPP_TRY(split(c->stem.w, (size_t)c->stem.cout * 64, c->stem.h2s));
     for (ConvDesc* d : all_convs(c)) OPP_TRY(split(d->w, d->w_floats(), d->h2s));
@@ -372,9 +401,10 @@ namespace {
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
              float* y, hipStream_t s, int h2, int tile_cfg = -1) {
   OppGemm g;
+  g.nonfinite = t_status_flag;
   g.conv = 1;
-  g.h2 = h2;
-  g.h2_inv = (h2 && d.h2s) ? d.h2s + 1 : nullptr;
+  g.prec = h2;
+  g.h2_inv = (h2 == OPP_PREC_FP16X2 && d.h2s) ? d.h2s + 1 : nullptr;
   g.A0 = x;
   g.Bn = 1;
   g.Hin = Hin;
@@ -386,10 +416,10 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.Hout = (Hin + 2 * g.pad - d.ks) / stride + 1;
   g.Wout = (Win + 2 * g.pad - d.ks) / stride + 1;
   g.W = d.w;
-  g.ldw = d.ks * d.ks * d.cin_pad();
+  g.K = d.ks * d.ks * d.cin_pad();
+  g.ldw = (int)split_floats((size_t)g.K, h2);
   g.M = g.Hout * g.Wout;
   g.N = d.cout_pad();
-  g.K = g.ldw;
   g.C = y;
   g.ldc = d.cout_pad();
   g.n_store = d.cout_pad();
@@ -460,16 +490,18 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     return OPP_ERR_WORKSPACE;
   }
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
-  const int hp = c->cfg.gemm_precision ? 1 : 0;
+  const int hp = gemm_prec(c->cfg);
   // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
   OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
   {
     OppGemm g;
+    g.nonfinite = t_status_flag;
+  g.nonfinite = t_status_flag;
     g.A0 = b.col;
     g.lda0 = 64;
     g.ksplit = 64;
     g.W = c->stem.w;
-    g.ldw = 64;
+    g.ldw = (int)split_floats(64, hp);
     g.M = H2 * W2;
     g.N = c->stem.cout;
     g.K = 64;
@@ -478,8 +510,8 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     g.n_store = pad32(c->stem.cout);
     g.bias = c->stem.bias;
     g.act = OPP_ACT_RELU;
-    g.h2 = hp;
-    g.h2_inv = hp ? c->stem.h2s + 1 : nullptr;
+    g.prec = hp;
+    g.h2_inv = hp == OPP_PREC_FP16X2 ? c->stem.h2s + 1 : nullptr;
     OPP_TRY(opp_gemm_launch(g, s));
   }
   OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s, hp));   // layer1 (:144)
@@ -510,6 +542,7 @@ extern "C" size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W)
 
 extern "C" int opp_backbone(opp_ctx* ctx, const float* image, int H, int W, float* feat_c, float* feat_f, void* ws,
                             size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && image && feat_c && feat_f && ws, "backbone: null argument");
   Arena a(ws, ws_bytes);
   return backbone_impl(ctx, image, H, W, feat_c, feat_f, a, (hipStream_t)stream);
@@ -587,8 +620,9 @@ struct LnArgs {   // LayerNorm fused into the GEMM epilogue (output rows = whole
 int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit, const float* W, int M, int N, int K, float* C,
                int act, hipStream_t s, int h2, const float* h2s, const LnArgs* ln = nullptr) {
   OppGemm g;
-  g.h2 = h2;
-  g.h2_inv = (h2 && h2s) ? h2s + 1 : nullptr;
+  g.nonfinite = t_status_flag;
+  g.prec = h2;
+  g.h2_inv = (h2 == OPP_PREC_FP16X2 && h2s) ? h2s + 1 : nullptr;
   if (ln) {
     g.ln_gamma = ln->gamma;
     g.ln_beta = ln->beta;
@@ -602,7 +636,7 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
   g.lda1 = lda1;
   g.ksplit = ksplit;
   g.W = W;
-  g.ldw = K;
+  g.ldw = (int)split_floats((size_t)K, h2);
   g.M = M;
   g.N = N;
   g.K = K;
@@ -637,11 +671,14 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     const bool cross = is_cross[li] != 0;
     {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
       OppGemm g;
+    g.nonfinite = t_status_flag;
+      g.nonfinite = t_status_flag;
+  g.nonfinite = t_status_flag;
       g.A0 = X;
       g.lda0 = C;
       g.ksplit = C;
       g.W = e.wqkv;
-      g.ldw = C;
+      g.ldw = (int)split_floats((size_t)C, h2);
       g.M = T;
       g.N = 3 * C;
       g.K = C;
@@ -653,8 +690,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.split_row = T0;
       g.s0 = (float)len0;
       g.s1 = (float)len1;
-      g.h2 = h2;
-      g.h2_inv = (h2 && e.sqkv) ? e.sqkv + 1 : nullptr;
+      g.prec = h2;
+      g.h2_inv = (h2 == OPP_PREC_FP16X2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
     }
     const float* q0 = b.qkv;
@@ -722,12 +759,13 @@ extern "C" size_t opp_transformer_workspace_bytes(const opp_ctx* ctx, int which,
 
 extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg, int len0, int len1, void* ws,
                                size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && ctx->packed && tokens && ws, "transformer: null argument");
   OPP_CHECK_ARG(which == 0 || which == 1, "transformer: which must be 0 or 1");
   Arena a(ws, ws_bytes);
   if (which == 0)
-    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, ctx->cfg.gemm_precision ? 1 : 0);
-  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, ctx->cfg.gemm_precision ? 1 : 0);
+    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg));
+  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -741,8 +779,8 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   const int C = c->cfg.coarse_d_model, L = hc * wc;
   float* scratch = a.f(opp_coarse_match_scratch_floats(n, L));
   float* stats = a.f(opp_coarse_match_stats_floats(n, L));
-  const bool h2 = c->cfg.gemm_precision >= 2;          // score GEMM on the fp16x2 path as well
-  float* f2_split = h2 ? a.f((size_t)L * C) : nullptr;
+  const int sprec = score_prec(c->cfg);                // score GEMM on the split-operand path as well
+  float* f2_split = sprec != OPP_PREC_FP32 ? a.f(split_floats((size_t)L * C, sprec)) : nullptr;
   if (!a.ok) {
     opp_set_error("coarse_match: workspace too small");
     return OPP_ERR_WORKSPACE;
@@ -750,6 +788,7 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   // sim = (f3/sqrt(C)) . (f2/sqrt(C)) / (temperature + 1e-4)   (coarse_matching.py:99-107).
   // C = 256: the 1/16 feature scaling is an exact power of two, so it commutes with the sum.
   OppGemm g;
+  g.nonfinite = t_status_flag;
   g.A0 = f3;
   g.lda0 = C;
   g.ksplit = C;
@@ -770,12 +809,15 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
     g.stat_colmax = g.stat_rowsum + (size_t)n * tn;
     g.stat_colsum = g.stat_colmax + tm * (size_t)L;
   }
-  if (h2) {   // the image tokens are the "weight" operand here: split them once per image (4 MB), unscaled
-    OPP_TRY(opp_h2_split(f2, f2_split, (size_t)L * C, nullptr, s));
+  if (sprec != OPP_PREC_FP32) {   // the image tokens are the "weight" operand here: split them once per image (4 / 6 MB), unscaled
+    if (sprec == OPP_PREC_BF16X3) OPP_TRY(opp_b3_split(f2, f2_split, (size_t)L * C, s));
+    else OPP_TRY(opp_h2_split(f2, f2_split, (size_t)L * C, nullptr, s));
     g.W = f2_split;
-    g.h2 = 1;
+    g.ldw = (int)split_floats((size_t)C, sprec);
+    g.prec = sprec;
   }
-  OPP_TRY(opp_gemm_launch_cfg(g, 0, s));   // 128x128 tiles: the partial layout above assumes them
+  // 128x128 tiles: the partial layout above assumes them (bf16x3: the 8-wave variant)
+  OPP_TRY(opp_gemm_launch_cfg(g, sprec == OPP_PREC_BF16X3 ? 25 : 0, s));
   return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, stats, scratch, i_ids, j_ids,
                                  mconf, mkpts_c, mkpts_3d, count, s);
 }
@@ -786,12 +828,13 @@ extern "C" size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n, in
   (void)ctx;
   return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) +
          opp_align(opp_coarse_match_stats_floats(n, L) * sizeof(float)) +
-         opp_align((size_t)L * 256 * sizeof(float)) + 1024;
+         opp_align((size_t)L * 256 * sizeof(float) * 3 / 2) + 1024;
 }
 
 extern "C" int opp_coarse_match(opp_ctx* ctx, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts,
                                 float base_scale, const float* qscale, float* conf, long long* i_ids, long long* j_ids, float* mconf,
                                 float* mkpts_c, float* mkpts_3d, int* count, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && f3 && f2 && kpts && conf && i_ids && j_ids && mconf && mkpts_c && mkpts_3d && count && ws,
                 "coarse_match: null argument");
   OPP_CHECK_ARG(n > 0 && hc > 0 && wc > 0, "coarse_match: empty input");
@@ -834,6 +877,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
                                   const float* qscale, float* feat_f, float* conf,
                                   long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d,
                                   int* count, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && (bank_c || tokens3d_pre) && feat_f && conf && ws, "forward_coarse: null argument");
   OPP_CHECK_ARG(n > 0, "forward_coarse: empty point cloud");
   OPP_CHECK_ARG(!ctx->cfg.pos_enc_enable || pe, "forward_coarse: positional encoding enabled but pe is null");
@@ -851,7 +895,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   a.off = mark;
   OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;
-  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, ctx->cfg.gemm_precision ? 1 : 0));
+  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg)));
   a.off = mark;
   return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
                            mkpts_3d, count, a, s);
@@ -869,6 +913,7 @@ extern "C" size_t opp_fine_workspace_bytes(const opp_ctx* ctx, int M) {
 extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* bank_f, int n, const long long* i_ids,
                         const long long* j_ids, int M, int hc, int wc, const float* mkpts_c, float base_scale,
                         const float* qscale, int run_transformer, float* expec_f, float* mkpts_f, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
   if (M <= 0) return OPP_OK;
   OPP_CHECK_ARG(ctx && ctx->packed && feat_f && bank_f && i_ids && j_ids && mkpts_c && expec_f && mkpts_f && ws,
                 "fine: null argument");
@@ -884,7 +929,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
   float* f3 = X + (size_t)M * WW * C;
   OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
   if (run_transformer)
-    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, ctx->cfg.gemm_precision ? 1 : 0));
+    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg)));
   const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
   return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
 }
@@ -894,8 +939,9 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
 // ----------------------------------------------------------------------------------------
 extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed, const float* bias,
                                int cout_pad, int ks, int stride, const float* residual, int res_mode, int act, float* y,
-                               int tile_cfg, int h2, const float* h2_scale, void* stream) {
+                               int tile_cfg, int prec, const float* h2_scale, void* stream) {
   OPP_CHECK_ARG(x && w_packed && y, "conv2d: null argument");
+  OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "conv2d: prec must be 0 (fp32), 1 (fp16x2) or 2 (bf16x3)");
   OPP_CHECK_ARG(cin_pad % 32 == 0 && cout_pad % 32 == 0, "conv2d: channel counts must be padded to 32");
   ConvDesc d;
   d.cin = cin_pad;
@@ -904,7 +950,7 @@ extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, co
   d.w = const_cast<float*>(w_packed);
   d.bias = const_cast<float*>(bias);
   d.h2s = const_cast<float*>(h2_scale);
-  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, h2 ? 1 : 0, tile_cfg);
+  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, prec, tile_cfg);
 }
 
 extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
@@ -917,16 +963,23 @@ extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2,
   return opp_h2_split(in, out, n, scale2, (hipStream_t)stream);
 }
 
-extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, int h2,
+extern "C" int opp_pack_b3(const float* in, float* out, size_t n, void* stream) {
+  OPP_CHECK_ARG(in && out, "pack_b3: null argument");
+  return opp_b3_split(in, out, n, (hipStream_t)stream);
+}
+
+extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, int prec,
                           const float* h2_scale, void* stream) {
+  OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "linear: prec must be 0 (fp32), 1 (fp16x2) or 2 (bf16x3)");
   OppGemm g;
-  g.h2 = h2 ? 1 : 0;
-  g.h2_inv = (h2 && h2_scale) ? h2_scale + 1 : nullptr;
+  g.nonfinite = t_status_flag;
+  g.prec = prec;
+  g.h2_inv = (prec == OPP_PREC_FP16X2 && h2_scale) ? h2_scale + 1 : nullptr;
   g.A0 = A;
   g.lda0 = K;
   g.ksplit = K;
   g.W = W;
-  g.ldw = K;
+  g.ldw = (int)split_floats((size_t)K, prec);
   g.M = M;
   g.N = N;
   g.K = K;
@@ -938,17 +991,19 @@ extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, i
 }
 
 extern "C" int opp_linear_layernorm(const float* A, int M, int K, const float* W, int N, const float* gamma, const float* beta,
-                                   const float* residual, float* C, int h2, const float* h2_scale, void* stream) {
+                                   const float* residual, float* C, int prec, const float* h2_scale, void* stream) {
   OPP_CHECK_ARG(A && W && gamma && beta && C, "linear_layernorm: null argument");
   OPP_CHECK_ARG(N == 256 || N == 128, "linear_layernorm: N must be 256 or 128");
+  OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "linear_layernorm: prec must be 0, 1 or 2");
   OppGemm g;
-  g.h2 = h2 ? 1 : 0;
-  g.h2_inv = (h2 && h2_scale) ? h2_scale + 1 : nullptr;
+  g.nonfinite = t_status_flag;
+  g.prec = prec;
+  g.h2_inv = (prec == OPP_PREC_FP16X2 && h2_scale) ? h2_scale + 1 : nullptr;
   g.A0 = A;
   g.lda0 = K;
   g.ksplit = K;
   g.W = W;
-  g.ldw = K;
+  g.ldw = (int)split_floats((size_t)K, prec);
   g.M = M;
   g.N = N;
   g.K = K;

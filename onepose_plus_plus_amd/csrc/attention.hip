@@ -12,7 +12,7 @@
 //
 // Token streams are regular: a stream is [n_seg][seg_len][ld] (coarse: one segment of 4096
 // image cells and one of N points; fine: M segments of 25 window cells and M of 1 point).
-#include "opp_common.h"
+#include "opp_internal.h"
 
 namespace {
 
@@ -464,7 +464,10 @@ int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv,
   const int c0 = opp_cdiv(len0, kPairChunk), c1 = opp_cdiv(len1, kPairChunk);
   float* kvp = scratch;
   float* ksp = scratch + (size_t)(c0 + c1) * 8192;
-  hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(64), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
+  {  // algorithmic bytes: K and V of every token read once + the chunk partials written
+    OppProfScope prof(OPP_PROF_LINATTN_KV, stream, (double)(len0 + len1) * 512.0 * 4.0 + (double)(c0 + c1) * (8192 + 256) * 4.0);
+    hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(64), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
+  }
   hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 64), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
   OPP_CHECK_LAUNCH("linattn_kv_pair");
   return OPP_OK;
@@ -473,6 +476,7 @@ int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv,
 int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
                            int len0, int len1, float eps, hipStream_t stream) {
   const int c0 = opp_cdiv(len0, kApplyChunk), c1 = opp_cdiv(len1, kApplyChunk);
+  OppProfScope prof(OPP_PROF_LINATTN_APPLY, stream, (double)(len0 + len1) * 256.0 * 4.0 * 2.0);   // Q read + message written
   hipLaunchKernelGGL(linattn_apply_pair_kernel, dim3(c0 + c1), dim3(256), 0, stream, qkv, ld, kv, ks, cross, out, ldo, len0, len1,
                      c0, eps);
   OPP_CHECK_LAUNCH("linattn_apply_pair_kernel");

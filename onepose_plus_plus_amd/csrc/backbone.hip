@@ -123,6 +123,36 @@ __global__ void h2_split_kernel(const float* __restrict__ in, uint4* __restrict_
   }
 }
 
+// bf16x3 pre-split of a GEMM operand (K-contiguous rows, K % 8 == 0): every 8 consecutive fp32 values become
+// 48 bytes [hi x8 | mid x8 | lo x8] with hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = bf16(x - hi - mid):
+// x = hi + mid + lo exactly (both residuals are exact fp32 subtractions, the last one has <= 8 significant bits)
+__device__ __forceinline__ unsigned b3_level(float a, float b, float& ra, float& rb) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 t = {a, b};
+  const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+  ra = a - __uint_as_float(p << 16);
+  rb = b - __uint_as_float(p & 0xffff0000u);
+  return p;
+}
+__global__ void b3_split_kernel(const float* __restrict__ in, uint4* __restrict__ out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float r0, r1, s0, s1, u0, u1;
+      hi[k] = b3_level(v[2 * k], v[2 * k + 1], r0, r1);
+      mid[k] = b3_level(r0, r1, s0, s1);
+      lo[k] = b3_level(s0, s1, u0, u1);
+    }
+    out[3 * i] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[3 * i + 1] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    out[3 * i + 2] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // out[i] = a[i] + b[i]   (float4 granularity; sizes multiple of 4)
 __global__ void add4_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -192,6 +222,15 @@ int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream
   const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
   hipLaunchKernelGGL(h2_split_kernel, dim3(blocks), dim3(256), 0, stream, in, reinterpret_cast<uint4*>(out), n8, scale2);
   OPP_CHECK_LAUNCH("h2_split_kernel");
+  return OPP_OK;
+}
+
+int opp_b3_split(const float* in, float* out, size_t n, hipStream_t stream) {
+  OPP_CHECK_ARG(n % 8 == 0 && in != out, "b3_split: n %% 8 != 0 or in-place");
+  const size_t n8 = n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(b3_split_kernel, dim3(blocks), dim3(256), 0, stream, in, reinterpret_cast<uint4*>(out), n8);
+  OPP_CHECK_LAUNCH("b3_split_kernel");
   return OPP_OK;
 }
 

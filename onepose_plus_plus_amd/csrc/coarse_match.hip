@@ -12,7 +12,7 @@
 //   matches ordered by ascending i, first surviving j per row (quirk q9)   (:166-172)
 // All equality tests are done on the conf values this code itself wrote, so the decision is
 // self-consistent (SURVEY.md §7 "hard parts").
-#include "opp_common.h"
+#include "opp_internal.h"
 
 namespace {
 
@@ -475,7 +475,10 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   const size_t conf_lds = fuse_cmax ? (size_t)L * 4 : 0;
   float* cpart = fuse_cmax ? part : nullptr;
   if (vec4 && fuse_cmax && L <= 16 * 256)
+  {
+    OppProfScope prof(OPP_PROF_CONF, stream, (double)N * (double)L * 8.0);   // score matrix read + confidence matrix written
     hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  }
   else if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
   else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
   if (fuse_cmax) {

@@ -29,26 +29,34 @@
 
 #include <vector>
 
-#include "opp_common.h"
+#include "opp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int kLdsStride = 36;  // floats per LDS tile row: 32 + 4 pad (keeps 16 B alignment)
+// floats per LDS tile row of one 32-k chunk: fp32 / fp16x2 32 + 4 pad; bf16x3 48 + 4 pad (both keep 16 B
+// alignment and make the 16 rows of a ds_read_b128 lane group land on 16 distinct 4-bank groups)
+constexpr int lds_stride(int prec) { return prec == OPP_PREC_BF16X3 ? 52 : 36; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, bool H2 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_FP32>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
+  constexpr bool H2 = PREC == OPP_PREC_FP16X2;   // operands as hi+lo fp16 pairs, 3 fp16 MFMA products
+  constexpr bool H3 = PREC == OPP_PREC_BF16X3;   // operands as hi+mid+lo bf16 triples (exact), 6 bf16 MFMA products
+  constexpr int kLdsStride = lds_stride(PREC);
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int NT32 = BN / 32;                               // 32-column sub-tiles per block
   constexpr int TN = (NT32 + WAVES_N - 1) / WAVES_N;          // per wave (last wave may own fewer)
   constexpr bool kRagged = (NT32 % WAVES_N) != 0;             // e.g. 224 columns on 2 waves = 4 + 3
   constexpr int A_LD = BM * 8 / NT;
-  constexpr int B_LD = BN * 8 / NT;
+  constexpr int B_LD = H3 ? BN * 12 / NT : BN * 8 / NT;   // bf16x3 weights: 192 B per row and chunk
   static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "load split");
+  static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 : (BN * 8) % NT == 0), "load split");
 
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (ABL == 9 || ABL > 90) ts0 = __builtin_readcyclecounter();
@@ -123,10 +131,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     }
   }
   unsigned b_base[B_LD];
+  int b_lds[B_LD];   // LDS float offset of the slot inside the B tile
 #pragma unroll
   for (int i = 0; i < B_LD; ++i) {
-    const int n = n0 + lrow + i * (NT / 8);
-    b_base[i] = n < g.N ? (unsigned)(n * g.ldw + kq * 4) * 4u : kOob;
+    if (H3) {   // pre-split weights: a row's chunk is 12 x 16 B ([hi x8 | mid x8 | lo x8] per 8 k)
+      const int u = tid + i * NT;
+      const int row = u / 12, c = u - row * 12;
+      const int n = n0 + row;
+      b_base[i] = n < g.N ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
+      b_lds[i] = row * kLdsStride + c * 4;
+    } else {
+      const int n = n0 + lrow + i * (NT / 8);
+      b_base[i] = n < g.N ? (unsigned)(n * g.ldw + kq * 4) * 4u : kOob;
+      b_lds[i] = (lrow + i * (NT / 8)) * kLdsStride + kq * 4;
+    }
   }
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       }
     } else {
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, live ? g.w_bytes : 0, 0x00020000);
-      b_reg[i - A_LD] = bload(r, b_base[i - A_LD] + (unsigned)cur_k0 * 4u);
+      b_reg[i - A_LD] = bload(r, b_base[i - A_LD] + (unsigned)cur_k0 * (H3 ? 6u : 4u));
     }
   };
   auto load_global = [&](float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
@@ -221,10 +239,41 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     hi = make_uint2(h01, h23);
     lo = make_uint2(l01, l23);
   };
+  // bf16x3 mode (H3): x = hi + mid + lo EXACTLY, hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = bf16(x - hi - mid)
+  // (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|, the last residual has <= 8 significant bits).  A 32-k chunk of a row is
+  // 192 B: four groups of 8 k, each [hi x8 | mid x8 | lo x8].  v_cvt_pk_bf16_f32 + shift/mask + subtract per level.
+  auto split_b3 = [](const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+    auto lvl = [](float a, float b, float& ra, float& rb) -> unsigned {
+      const f32x2 t = {a, b};
+      const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+      ra = a - __uint_as_float(p << 16);
+      rb = b - __uint_as_float(p & 0xffff0000u);
+      return p;
+    };
+    float r0, r1, r2, r3, s0, s1, s2, s3, u0, u1, u2, u3;
+    const unsigned h01 = lvl(v.x, v.y, r0, r1), h23 = lvl(v.z, v.w, r2, r3);
+    const unsigned m01 = lvl(r0, r1, s0, s1), m23 = lvl(r2, r3, s2, s3);
+    const unsigned l01 = lvl(s0, s1, u0, u1), l23 = lvl(s2, s3, u2, u3);
+    hi = make_uint2(h01, h23);
+    mid = make_uint2(m01, m23);
+    lo = make_uint2(l01, l23);
+  };
   auto store_item = [&](int i, int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
     if (i < A_LD) {
       float* row = As + buf * BM * kLdsStride + (lrow + i * (NT / 8)) * kLdsStride;
-      if (H2) {
+      if (H3) {
+        uint2 hi, mid, lo;
+        if (ABL == 95) {   // ablation: no split arithmetic (wrong results, timing only)
+          hi = make_uint2(__float_as_uint(a_reg[i].x), __float_as_uint(a_reg[i].y));
+          mid = make_uint2(__float_as_uint(a_reg[i].z), __float_as_uint(a_reg[i].w));
+          lo = hi;
+        } else
+        split_b3(a_reg[i], hi, mid, lo);
+        float* dst = row + (kq >> 1) * 12 + (kq & 1) * 2;     // group kq/2, elements (kq&1)*4 .. +3 of each part
+        *reinterpret_cast<uint2*>(dst) = hi;
+        *reinterpret_cast<uint2*>(dst + 4) = mid;
+        *reinterpret_cast<uint2*>(dst + 8) = lo;
+      } else if (H2) {
         uint2 hi, lo;
         split_h2(a_reg[i], hi, lo);
         float* dst = row + (kq >> 1) * 8 + (kq & 1) * 2;      // group kq/2, elements (kq&1)*4 .. +3
@@ -234,7 +283,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         *reinterpret_cast<float4*>(row + kq * 4) = a_reg[i];
       }
     } else {
-      *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + (lrow + (i - A_LD) * (NT / 8)) * kLdsStride + kq * 4) = b_reg[i - A_LD];
+      *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
     }
   };
   auto store_lds = [&](int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
@@ -251,13 +300,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fp32: lane half h owns k in [16h, 16h+16) of the chunk; fp16x2: it owns k-group 2s+h of k16-step s
-  const int a_frag = (wm * TM * 32 + l31) * kLdsStride + half * (H2 ? 8 : 16);
-  const int b_frag = (wn * TN * 32 + l31) * kLdsStride + half * (H2 ? 8 : 16);
+  // bf16x3: as fp16x2 with 12-float groups
+  const int a_frag = (wm * TM * 32 + l31) * kLdsStride + half * (H3 ? 12 : H2 ? 8 : 16);
+  const int b_frag = (wn * TN * 32 + l31) * kLdsStride + half * (H3 ? 12 : H2 ? 8 : 16);
 
   // LDS -> MFMA operand fragments of ONE k-quarter (8 k values: 4 per lane half) of a chunk
   // (fp16x2: q = 2*step + part, part 0 = the 8 hi halves, 1 = the 8 lo halves of this lane's k-group)
   auto read_frags = [&](int buf, int q, float4 (&af)[TM], float4 (&bf)[TN]) {
-    const int qoff = H2 ? (q >> 1) * 16 + (q & 1) * 4 : q * 4;
+    // bf16x3: q = 3*step + part (part 0/1/2 = the hi/mid/lo halves of this lane's k-group)
+    const int qoff = H3 ? (q / 3) * 24 + (q % 3) * 4 : H2 ? (q >> 1) * 16 + (q & 1) * 4 : q * 4;
     const float* as = As + buf * BM * kLdsStride + a_frag + qoff;
     const float* bs = Bs + buf * BN * kLdsStride + b_frag + qoff;
 #pragma unroll
@@ -306,7 +357,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   //   read q0 of chunk c+1 | MFMA q3                          -- covers barrier skew + LDS latency
   // so the matrix pipe never waits for a global load, an LDS write or the barrier.
   float4 ga[DEPTH][A_LD], gb[DEPTH][B_LD];   // DEPTH chunks of global prefetch in registers
-  float4 fa[4][TM], fb[4][TN];   // fp32 uses sets 0,1 ; fp16x2 uses (0,1) = hi/lo of step 0, (2,3) of step 1
+  // fp32 uses sets 0,1 ; fp16x2 (0,1) = hi/lo of step 0, (2,3) of step 1 ; bf16x3 (0,1,2) = hi/mid/lo of step 0, (3,4,5) of step 1
+  float4 fa[H3 ? 6 : 4][TM], fb[H3 ? 6 : 4][TN];
   float4 da[A_LD], db[B_LD];   // ablation 5 only: load sink that is never consumed in the loop
 
 #pragma unroll
@@ -317,7 +369,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   store_lds(0, ga[0], gb[0]);
   __syncthreads();
   read_frags(0, 0, fa[0], fb[0]);
-  if (H2) read_frags(0, 1, fa[1], fb[1]);
+  if (H2 || H3) read_frags(0, 1, fa[1], fb[1]);
+  if constexpr (H3) read_frags(0, 2, fa[2], fb[2]);
 
   // The chunk body has no branches: the waitcnt pass can prove that the chunk c+1 registers are
   // the OLDEST loads in flight and waits with a counted vmcnt instead of draining the freshly
@@ -438,10 +491,84 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  // ---- bf16x3 variant of the chunk: 2 k16-steps of v_mfma_f32_32x32x16_bf16, six products per tile pair and
+  // step (lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi, fp32 accumulate; the dropped mid*lo, lo*mid, lo*lo
+  // terms are <= 2^-26 |a||b|): 6/16 of the fp32 MFMA cycles, operands carried exactly ------
+  auto as_b8 = [](const float4& v) { return *reinterpret_cast<const bf16x8*>(&v); };
+  // products [p0, p1) of step `st` (fragment sets 3*st + {0 hi, 1 mid, 2 lo}), smallest terms first
+  auto mfma_b3 = [&](int st, int p0, int p1, auto&& between) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    int n = 0;
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      if (pr < p0 || pr >= p1) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (tile_ok[j])
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[(H3 ? 3 : 0) * st + PA[pr]][i]), as_b8(fb[(H3 ? 3 : 0) * st + PB[pr]][j]), acc[i][j], 0, 0, 0);
+          between(n);
+          ++n;
+        }
+    }
+  };
+  constexpr int kSlots3L = 6 * TM * TN;                   // step 0: all six products
+  constexpr int kStride3L = kSlots3L / kItems > 0 ? kSlots3L / kItems : 1;
+  constexpr int kSlots3S = 4 * TM * TN;                   // step 1: first four products
+  constexpr int kStride3S = kSlots3S / kItems > 0 ? kSlots3S / kItems : 1;
+  auto chunk_h3 = [&](auto set, int lb) {
+    constexpr int P = decltype(set)::value;
+    constexpr int PN = (P + 1) % DEPTH;
+    const int B0 = lb, B1 = lb ^ 1;
+    advance();
+    if (ABL != 94) {
+      read_frags(B0, 3, fa[H3 ? 3 : 0], fb[H3 ? 3 : 0]);
+      read_frags(B0, 4, fa[H3 ? 4 : 0], fb[H3 ? 4 : 0]);
+      read_frags(B0, 5, fa[H3 ? 5 : 0], fb[H3 ? 5 : 0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_b3(0, 0, 6, [&](int n) {                    // step 0 + prefetch of chunk c+DEPTH, one load per slot
+      if (n % kStride3L == 0 && n / kStride3L < kItems) {
+        if (ABL != 91) load_item(n / kStride3L, ga[P], gb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int i = kSlots3L / kStride3L; i < kItems; ++i)
+      if (ABL != 91) load_item(i, ga[P], gb[P]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_b3(1, 0, 4, [&](int n) {                    // step 1, first four products + LDS hand-over of chunk c+1
+      if (n % kStride3S == 0 && n / kStride3S < kItems) {
+        if (ABL != 92) store_item(n / kStride3S, B1, ga[PN], gb[PN]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int i = kSlots3S / kStride3S; i < kItems; ++i)
+      if (ABL != 92) store_item(i, B1, ga[PN], gb[PN]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 93) __syncthreads();
+    if (ABL != 94) {
+      read_frags(B1, 0, fa[0], fb[0]);
+      read_frags(B1, 1, fa[1], fb[1]);
+      read_frags(B1, 2, fa[2], fb[2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_b3(1, 4, 6, nothing);                       // step 1 hi*mid + hi*hi cover the barrier + LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   if (ABL == 9 || ABL > 90) ts1 = __builtin_readcyclecounter();
   // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
   for (int c = 0; c < nk; c += DEPTH) {
-    if (H2) {
+    if constexpr (H3) {
+      chunk_h3(std::integral_constant<int, 0>{}, c & 1);
+      if (DEPTH > 1) chunk_h3(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+      if (DEPTH > 2) chunk_h3(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
+      if (DEPTH > 3) chunk_h3(std::integral_constant<int, 3 % DEPTH>{}, (c + 3) & 1);
+    } else if constexpr (H2) {
       chunk_h2(std::integral_constant<int, 0>{}, c & 1);
       if (DEPTH > 1) chunk_h2(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
       if (DEPTH > 2) chunk_h2(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
@@ -490,6 +617,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           const float cv0 = H2 ? acc[i][j][r] * h2_inv : acc[i][j][r];
           acc[i][j][r] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
         }
+  }
+  if constexpr (H2) {
+    if (g.nonfinite != nullptr) {   // range guard: |x| beyond the fp16 range shows up as inf / NaN accumulators
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bad |= !(fabsf(acc[i][j][r]) <= 3.4028235e38f);
+      if (__builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) atomicOr(g.nonfinite, 1);
+    }
   }
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
@@ -779,25 +918,68 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   }
 }
 
-// ---- optional live profiling of one kernel symbol (tile config x conv/dense) with HIP events ----
-struct GemmProfiler {
-  bool on = false;
-  int cfg = -1, conv = -1;
-  std::vector<hipEvent_t> ev;   // pairs (start, stop)
-  size_t used = 0;              // events used
-  double flops = 0.0;
-  long long dropped = 0;
-  std::mutex mu;                // forwards may be in flight from several host threads / streams
-} g_prof;
+template <typename K>
+void set_lds_once(K k, size_t lds, bool& done) {
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
+  }
+}
 
-unsigned long long* g_dbg_ts = nullptr;   // tuning: opp_debug_timestamps()
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH, int PREC>
+int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  // split-operand variants are built for the 64/128/256-column tiles (bf16x3: 12 x 16 B weight slots per row
+  // must divide over the workgroup; its 4-wave 128x128 tile would not fit the register file)
+  constexpr bool ok = PREC == OPP_PREC_FP32 ||
+                      ((BN == 128 || BN == 64 || BN == 256) &&
+                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 32 && NT <= 512)));
+  if constexpr (ok) {
+    const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
+    const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
+    if (g.conv) {
+      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, PREC>;
+      static bool attr_done = false;
+      set_lds_once(k, lds, attr_done);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+    } else {
+      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH, PREC>;
+      static bool attr_done = false;
+      set_lds_once(k, lds, attr_done);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+    }
+    OPP_CHECK_LAUNCH("opp_gemm_kernel");
+    return OPP_OK;
+  } else {
+    opp_set_error("gemm: tile %dx%d on %d waves is not built for operand precision %d", BM, BN, WAVES_M * WAVES_N, PREC);
+    return OPP_ERR_UNSUPPORTED;
+  }
+}
 
-template <int BM, int BN, int WM, int WN, bool H2, int ABL = 9>
-int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // tuning only: conv kernel with phase time stamps
+template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH = 2>
+int launch_cfg(const OppGemm& g, hipStream_t stream) {
+#ifdef OPP_TUNING
+  static const size_t extra_lds = getenv("OPP_EXTRA_LDS") ? (size_t)atoi(getenv("OPP_EXTRA_LDS")) : 0;  // tuning knob
+#else
+  constexpr size_t extra_lds = 0;
+#endif
+  switch (g.prec) {
+    case OPP_PREC_FP32: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_FP32>(g, stream, extra_lds);
+    case OPP_PREC_FP16X2: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_FP16X2>(g, stream, extra_lds);
+    case OPP_PREC_BF16X3: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_BF16X3>(g, stream, extra_lds);
+    default: opp_set_error("gemm: unknown operand precision %d", g.prec); return OPP_ERR_INVALID;
+  }
+}
+
+#ifdef OPP_TUNING
+unsigned long long* g_dbg_ts = nullptr;   // opp_debug_timestamps()
+
+template <int BM, int BN, int WM, int WN, int PREC, int ABL = 9>
+int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // conv kernel with phase time stamps
   OppGemm g = g_in;
   g.dbg_ts = g_dbg_ts;
-  const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float);
-  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, H2>;
+  const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float);
+  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, PREC>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN)), dim3(WM * WN * 64), lds, stream, g);
   OPP_CHECK_LAUNCH("opp_gemm_kernel(timed)");
@@ -805,8 +987,8 @@ int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // tuning only: co
 }
 
 template <int ABL>
-int launch_ablate(const OppGemm& g, hipStream_t stream) {   // tuning only: 128x128 conv with parts removed
-  const size_t lds = (size_t)2 * (128 + 128) * kLdsStride * sizeof(float);
+int launch_ablate(const OppGemm& g, hipStream_t stream) {   // fp32 128x128 conv with parts removed
+  const size_t lds = (size_t)2 * (128 + 128) * lds_stride(OPP_PREC_FP32) * sizeof(float);
   auto k = opp_gemm_kernel<128, 128, 2, 2, true, ABL>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128)), dim3(256), lds, stream, g);
@@ -814,66 +996,31 @@ int launch_ablate(const OppGemm& g, hipStream_t stream) {   // tuning only: 128x
   return OPP_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH>
-int launch_cfg_h2(const OppGemm& g, hipStream_t stream) {   // fp16x2-split operands (weights pre-split)
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  if constexpr (BN == 128 || BN == 64 || BN == 256) {
-    const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float);
-    const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
-    if (g.conv) {
-      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, true>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-      }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
-    } else {
-      auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH, true>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-      }
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
-    }
-    OPP_CHECK_LAUNCH("opp_gemm_kernel(fp16x2)");
-    return OPP_OK;
-  } else {
-    opp_set_error("gemm: the fp16x2 variant is built for the 128/64-column tiles only");
-    return OPP_ERR_UNSUPPORTED;
+// tuning-only tile configurations: phase-stamped convs (120/121/122), loop ablations (191-193, 101-107)
+int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
+  const bool h2 = g.prec == OPP_PREC_FP16X2, h3 = g.prec == OPP_PREC_BF16X3;
+  switch (cfg) {
+    case 120: return !g.conv ? OPP_ERR_INVALID : h3 ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3>(g, stream) : h2 ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2>(g, stream) : launch_timed<256, 128, 4, 2, OPP_PREC_FP32>(g, stream);
+    case 121: return !g.conv || h3 ? OPP_ERR_INVALID : h2 ? launch_timed<128, 128, 2, 2, OPP_PREC_FP16X2>(g, stream) : launch_timed<128, 128, 2, 2, OPP_PREC_FP32>(g, stream);
+    case 122: return !g.conv ? OPP_ERR_INVALID : h3 ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3>(g, stream) : h2 ? launch_timed<128, 128, 4, 2, OPP_PREC_FP16X2>(g, stream) : launch_timed<128, 128, 4, 2, OPP_PREC_FP32>(g, stream);
+    case 291: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 91>(g, stream) : OPP_ERR_INVALID;   // no global loads
+    case 292: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores / split
+    case 293: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
+    case 294: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 94>(g, stream) : OPP_ERR_INVALID;   // no LDS fragment reads
+    case 295: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 95>(g, stream) : OPP_ERR_INVALID;   // no split arithmetic
+    case 191: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 91>(g, stream) : OPP_ERR_INVALID;   // no global loads
+    case 192: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores
+    case 193: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
+    case 101: return g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID;
+    case 102: return g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID;
+    case 103: return g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID;
+    case 105: return g.conv ? launch_ablate<5>(g, stream) : OPP_ERR_INVALID;
+    case 106: return g.conv ? launch_ablate<6>(g, stream) : OPP_ERR_INVALID;
+    case 107: return g.conv ? launch_ablate<7>(g, stream) : OPP_ERR_INVALID;
+    default: opp_set_error("gemm: unknown tile config %d", cfg); return OPP_ERR_INVALID;
   }
 }
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH = 2>
-int launch_cfg(const OppGemm& g, hipStream_t stream) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  static const size_t extra_lds = getenv("OPP_EXTRA_LDS") ? (size_t)atoi(getenv("OPP_EXTRA_LDS")) : 0;  // tuning knob
-  const size_t lds = (size_t)2 * (BM + BN) * kLdsStride * sizeof(float) + extra_lds;
-  const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
-  if (g.h2) return launch_cfg_h2<BM, BN, WAVES_M, WAVES_N, DEPTH>(g, stream);
-  if (g.conv) {
-    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
-  } else {
-    auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
-  }
-  OPP_CHECK_LAUNCH("opp_gemm_kernel");
-  return OPP_OK;
-}
+#endif
 
 }  // namespace
 
@@ -885,13 +1032,19 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     if (g.res_mode != OPP_RES_NONE) v = v && g.ldr % 4 == 0 && al16(g.R);
     g.vec_epilogue = v ? 1 : 0;
   }
+#ifdef OPP_TUNING
   static const int xcd_env = getenv("OPP_XCD_SWIZZLE") ? atoi(getenv("OPP_XCD_SWIZZLE")) : 1;
   g.xcd_swizzle = xcd_env;
+#else
+  g.xcd_swizzle = 1;
+#endif
+  const bool split = g.prec != OPP_PREC_FP32;
   OPP_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm: bad M/N/K (%d,%d,%d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.n_store >= g.N && g.C && g.W && g.A0, "gemm: bad output/operands");
   OPP_CHECK_ARG((size_t)g.M * (size_t)g.ldc < (1ull << 31), "gemm: output too large for 32-bit indexing");
   g.w_bytes = (unsigned)((size_t)g.N * g.ldw * 4);
   OPP_CHECK_ARG((size_t)g.N * g.ldw * 4 < (1ull << 31), "gemm: weight operand too large for buffer addressing");
+  OPP_CHECK_ARG(g.prec != OPP_PREC_BF16X3 || g.ldw * 2 >= g.K * 3, "gemm: bf16x3 weights need a row stride of 1.5 K floats");
   if (g.conv) {
     OPP_CHECK_ARG(g.Cin % 32 == 0 && g.K == g.ksize * g.ksize * g.Cin, "conv: Cin %% 32 / K mismatch");
     OPP_CHECK_ARG(g.M == g.Bn * g.Hout * g.Wout, "conv: M != B*Hout*Wout");
@@ -918,28 +1071,26 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     else cfg = 2;
     // prefetch depth of the long-K convolutions on 128x128 tiles: 4 register sets when the grid
     // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
-    // (fp16x2: the MFMA phase is 5x shorter, depth 2 measured best on every layer)
-    if (g.conv && g.K >= 768 && cfg == 0 && !g.h2) cfg = t0 <= 512 ? 11 : 10;
+    // (split operands: the MFMA phase is shorter, depth 2 measured best on every layer)
+    if (g.conv && g.K >= 768 && cfg == 0 && !split) cfg = t0 <= 512 ? 11 : 10;
     // fp32, 128-column outputs of the 256x256-pixel layers: the 8-wave 128x128 tile (two waves per SIMD cover the
     // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
-    if (!g.h2 && t0 >= 384 && g.n_store <= 128) cfg = 25;
-    if (g.h2) {
-      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Default policy:
-      // 128x128 (73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel -- fits
-      // on the CU) wherever it still gives ~a workgroup per CU, else 64x128.  The 256x128 / 128x256 tiles
-      // (110 KB LDS) are 2-5 % faster for a kernel running alone on the two largest layers but cost 2.3 % of the
-      // throughput with three forwards in flight (no co-residency); OPP_H2_BIG_TILES=1 re-enables them,
-      // =0 falls back to the 4-wave tiles.
-      static const int big_env = getenv("OPP_H2_BIG_TILES") ? atoi(getenv("OPP_H2_BIG_TILES")) : 3;   // tuning knob
-      const int t22 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 256);
-      const int t20 = opp_cdiv(g.M, 256) * opp_cdiv(g.n_store, 128);
-      if (big_env == 1 && g.n_store > 128 && t22 >= 200) cfg = 22;
-      else if (big_env == 1 && t20 >= 200) cfg = 20;
-      else if (big_env && t0 >= 200) cfg = 25;      // 128x128 on 8 waves (32x64 per wave)
-      else if (big_env && t1 >= 512) cfg = 26;      // 64x128 on 8 waves
+    if (!split && t0 >= 384 && g.n_store <= 128) cfg = 25;
+    if (split) {
+      // fp16x2 / bf16x3: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Policy:
+      // 128x128 (fp16x2 73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel --
+      // fits on the CU) wherever it still gives ~a workgroup per CU, else 64x128, else the 4-wave 64x64 tile.
+      // The 256x128 / 128x256 fp16x2 tiles (110 KB LDS) are 2-5 % faster for a kernel running alone on the two
+      // largest layers but cost 2.3 % of the throughput with three forwards in flight (no co-residency).
+      if (t0 >= 200) cfg = 25;          // 128x128 on 8 waves (32x64 per wave)
+      else if (t1 >= 512) cfg = 26;     // 64x128 on 8 waves
+      else cfg = 2;
     }
   }
-  OPP_CHECK_ARG(g.stat_rowmax == nullptr || cfg == 0, "gemm: fused softmax statistics need the 128x128 tile");
+  // (the statistics scratch sits behind the staged C tile in the operand LDS: 4-wave tile for fp32 / fp16x2,
+  // 8-wave tile for bf16x3, whose operand buffers are larger)
+  OPP_CHECK_ARG(g.stat_rowmax == nullptr || (g.prec == OPP_PREC_BF16X3 ? cfg == 25 : cfg == 0),
+                "gemm: fused softmax statistics need the 128x128 tile (config 0; bf16x3: config 25)");
   if (g.ln_gamma != nullptr) {
     if (cfg < 0 || (cfg != 30 && cfg != 26)) cfg = g.n_store == 256 ? 30 : 26;
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -948,21 +1099,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
                       al(g.ln_beta) && (!g.ln_res || (al(g.ln_res) && g.ln_ldres % 4 == 0)),
                   "gemm: fused LayerNorm needs a 256- or 128-column output, no bias/activation/residual mode, aligned operands");
   }
-  const bool prof = g_prof.on && g_prof.cfg == cfg && g_prof.conv == (g.conv ? 1 : 0);
-  bool rec = false;
-  size_t slot = 0;
-  if (prof) {
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    if (g_prof.on && g_prof.used + 2 <= g_prof.ev.size()) {
-      slot = g_prof.used;
-      g_prof.used += 2;
-      g_prof.flops += g.alg_flops > 0.0 ? g.alg_flops : 2.0 * (double)g.M * (double)g.N * (double)g.K;
-      rec = true;
-    } else {
-      g_prof.dropped++;
-    }
-  }
-  if (rec) (void)hipEventRecord(g_prof.ev[slot], stream);
+  // live timing of this symbol when armed (bench.py roofline leg)
+  OppProfScope prof_scope(opp_prof_gemm_symbol(cfg, g.conv ? 1 : (g.stat_rowmax ? 2 : 0)), stream,
+                          g.alg_flops > 0.0 ? g.alg_flops : 2.0 * (double)g.M * (double)g.N * (double)g.K);
   int rc;
   switch (cfg) {
     case 0: rc = launch_cfg<128, 128, 2, 2>(g, stream); break;
@@ -970,7 +1109,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 2: rc = launch_cfg<64, 64, 2, 2>(g, stream); break;
     case 3: rc = launch_cfg<128, 224, 4, 1>(g, stream); break;
     case 5: rc = launch_cfg<64, 224, 2, 2>(g, stream); break;   // 4 waves: N split 128 + 96
-    case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // prefetch depth experiments
+    case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // deeper global prefetch (long-K fp32 convs)
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
     case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
@@ -979,73 +1118,29 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
     case 27: rc = launch_cfg<256, 128, 8, 2>(g, stream); break;     // 16 waves, 32x64 per wave
     case 28: rc = launch_cfg<128, 256, 4, 4>(g, stream); break;     // 16 waves, 32x64 per wave
-    case 120: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<256, 128, 4, 2, true>(g, stream) : launch_timed<256, 128, 4, 2, false>(g, stream); break;
-    case 121: rc = !g.conv ? OPP_ERR_INVALID : g.h2 ? launch_timed<128, 128, 2, 2, true>(g, stream) : launch_timed<128, 128, 2, 2, false>(g, stream); break;
-    case 191: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 91>(g, stream) : OPP_ERR_INVALID; break;   // no global loads
-    case 192: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 92>(g, stream) : OPP_ERR_INVALID; break;   // no LDS stores
-    case 193: rc = (g.conv && g.h2) ? launch_timed<256, 128, 4, 2, true, 93>(g, stream) : OPP_ERR_INVALID; break;   // no barrier
-    case 101: rc = g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID; break;
-    case 102: rc = g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID; break;
-    case 103: rc = g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID; break;
-    case 105: rc = g.conv ? launch_ablate<5>(g, stream) : OPP_ERR_INVALID; break;
-    case 106: rc = g.conv ? launch_ablate<6>(g, stream) : OPP_ERR_INVALID; break;
-    case 107: rc = g.conv ? launch_ablate<7>(g, stream) : OPP_ERR_INVALID; break;
-    default: opp_set_error("gemm: unknown tile config %d", cfg); return OPP_ERR_INVALID;
+    default:
+#ifdef OPP_TUNING
+      rc = launch_tuning_cfg(g, cfg, stream);
+#else
+      opp_set_error("gemm: unknown tile config %d", cfg);
+      rc = OPP_ERR_INVALID;
+#endif
+      break;
   }
-  if (rec) (void)hipEventRecord(g_prof.ev[slot + 1], stream);
   return rc;
 }
 
-// tuning: device buffer receiving 4 shader-clock stamps (entry, loop start, loop end, exit) per wave
-// of the timed conv variants (tile configs 120 / 121)
+// tuning builds (-DOPP_TUNING): device buffer receiving 4 shader-clock stamps (entry, loop start, loop end,
+// exit) per wave of the timed conv variants (tile configs 120-122); a no-op error otherwise
 extern "C" int opp_debug_timestamps(void* buf) {
+#ifdef OPP_TUNING
   g_dbg_ts = static_cast<unsigned long long*>(buf);
   return OPP_OK;
-}
-
-// Live measurement of one GEMM kernel symbol with HIP events recorded on the launch stream
-// (bench.py roofline leg).  start: arm for (tile_cfg, conv) with room for `capacity` launches.
-extern "C" int opp_profile_start(int tile_cfg, int conv, int capacity) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-  g_prof.ev.clear();
-  g_prof.ev.resize((size_t)capacity * 2);
-  for (auto& e : g_prof.ev)
-    if (hipEventCreate(&e) != hipSuccess) {
-      opp_set_error("profile: hipEventCreate failed");
-      return OPP_ERR_LAUNCH;
-    }
-  g_prof.used = 0;
-  g_prof.flops = 0.0;
-  g_prof.dropped = 0;
-  g_prof.cfg = tile_cfg;
-  g_prof.conv = conv;
-  g_prof.on = true;
-  return OPP_OK;
-}
-
-// stop: synchronises the recorded events; returns summed kernel time (ms), summed algorithmic
-// FLOPs and the number of launches measured.
-extern "C" int opp_profile_stop(double* total_ms, double* total_flops, int* launches) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = false;
-  double ms = 0.0;
-  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-    if (hipEventSynchronize(g_prof.ev[i + 1]) != hipSuccess) {
-      opp_set_error("profile: hipEventSynchronize failed");
-      return OPP_ERR_LAUNCH;
-    }
-    float t = 0.f;
-    (void)hipEventElapsedTime(&t, g_prof.ev[i], g_prof.ev[i + 1]);
-    ms += t;
-  }
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = g_prof.flops;
-  if (launches) *launches = (int)(g_prof.used / 2);
-  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
-  g_prof.ev.clear();
-  g_prof.used = 0;
-  return OPP_OK;
+#else
+  (void)buf;
+  opp_set_error("opp_debug_timestamps: library built without -DOPP_TUNING");
+  return OPP_ERR_UNSUPPORTED;
+#endif
 }
 
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream) { return opp_gemm_launch_cfg(g, -1, stream); }

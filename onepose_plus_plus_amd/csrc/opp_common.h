@@ -47,6 +47,11 @@ static inline size_t opp_align(size_t x, size_t a = 256) { return (x + a - 1) / 
 // the implicit im2col view of an NHWC activation tensor (3x3 / 1x1, stride 1 / 2).
 // ---------------------------------------------------------------------------------------
 enum { OPP_ACT_NONE = 0, OPP_ACT_RELU = 1, OPP_ACT_LEAKY = 2, OPP_ACT_QKV = 3 };
+// operand arithmetic of a GEMM launch (always fp32 accumulate, fp32 in / fp32 out):
+//   FP32    v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain
+//   FP16X2  x ~ hi + lo fp16 (22 significant bits, fp16 exponent range), 3 x v_mfma_f32_32x32x16_f16
+//   BF16X3  x = hi + mid + lo bf16 EXACTLY (24 bits, fp32 exponent range), 6 x v_mfma_f32_32x32x16_bf16
+enum { OPP_PREC_FP32 = 0, OPP_PREC_FP16X2 = 1, OPP_PREC_BF16X3 = 2 };
 enum { OPP_RES_NONE = 0, OPP_RES_DIRECT = 1, OPP_RES_BILINEAR2X = 2 };
 
 struct OppGemm {
@@ -81,11 +86,14 @@ struct OppGemm {
   float out_mul = 1.f, out_div = 1.f;
   // operand extents in bytes for the buffer descriptors (filled by the launcher)
   unsigned a0_bytes = 0, a1_bytes = 0, w_bytes = 0;
-  // 1 = fp16x2-split operands: W is pre-split ([hi x8 | lo x8] per 8 k), A is split on the fly;
-  // three v_mfma_f32_32x32x16_f16 products per k16-step, fp32 accumulate (22-bit operand mantissas)
-  int h2 = 0;
+  // OPP_PREC_*.  Split modes: W is pre-split per 8 consecutive k (fp16x2 [hi x8 | lo x8] = 32 B, same footprint as
+  // fp32; bf16x3 [hi x8 | mid x8 | lo x8] = 48 B, row stride ldw = 1.5 K floats), A is fp32 and split on the fly
+  int prec = OPP_PREC_FP32;
   const float* h2_inv = nullptr;   // device scalar: 1 / (power-of-two scale applied to W before the split), or null
-  unsigned long long* dbg_ts = nullptr;   // tuning builds (ABL 9): 4 shader-clock stamps per wave
+  // fp16x2 range guard: device int OR-ed with 1 when this launch produced a non-finite output (an activation
+  // beyond the fp16 range makes its lo half infinite); null = unchecked.  Unused by the other arithmetics.
+  int* nonfinite = nullptr;
+  unsigned long long* dbg_ts = nullptr;   // -DOPP_TUNING builds (ABL 9): 4 shader-clock stamps per wave
   int xcd_swizzle = 1;
   int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
   // optional softmax statistics of the OUTPUT tile (score GEMM of the coarse matcher): per row

@@ -2,6 +2,28 @@
 #pragma once
 #include "opp_common.h"
 
+// profile.hip -- HIP-event timing of one armed kernel symbol (opp_profile_start / opp_profile_stop)
+// symbol ids: GEMM / conv launches = kind * 256 + tile config (kind 0 dense, 1 implicit-GEMM conv, 2 coarse score
+// GEMM with the fused softmax statistics); the bandwidth-bound kernels have fixed ids from 1000 (work = bytes)
+enum {
+  OPP_PROF_FIRST_NON_GEMM = 1000,
+  OPP_PROF_LINATTN_KV = 1000,      // linattn_kv_mfma_kernel: the attention gather  sum_s phi(K_s)^T V_s
+  OPP_PROF_LINATTN_APPLY = 1001,   // linattn_apply_pair_kernel
+  OPP_PROF_CONF = 1002,            // conf_reg_kernel: dual-softmax product over the N x L score matrix
+  OPP_PROF_FINE = 1003,            // fine stage kernel(s)
+};
+inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
+struct OppProfScope {
+  OppProfScope(int symbol, hipStream_t stream, double work);
+  ~OppProfScope();
+  OppProfScope(const OppProfScope&) = delete;
+  OppProfScope& operator=(const OppProfScope&) = delete;
+
+ private:
+  hipStream_t stream_;
+  long long slot_ = -1;
+};
+
 // attention.hip
 int opp_layernorm(const float* x, int ldx, const float* gamma, const float* beta, const float* res, int ldres,
                   float* out, int ldo, int rows, int C, float eps, hipStream_t stream);
@@ -24,6 +46,8 @@ int opp_pack_stem(const float* w, const float* scale, int cout, float* out, hipS
 int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream_t stream);
 // fp16x2 pre-split; scale2 (device, 2 floats: scale, 1/scale) null = unscaled
 int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream_t stream);
+// bf16x3 pre-split: out holds 1.5 n floats (48 B per 8 values)
+int opp_b3_split(const float* in, float* out, size_t n, hipStream_t stream);
 int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
 int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream);
 // kpt.hip

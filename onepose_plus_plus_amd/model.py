@@ -138,8 +138,8 @@ def _validate_config(cfg):
         raise NotImplementedError()
 
 
-GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 2}
-DEFAULT_GEMM_PRECISION = "fp16x2_all"
+GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 2, "bf16x3": 3}
+DEFAULT_GEMM_PRECISION = "bf16x3"
 
 
 class OnePosePlus_model(nn.Module):
@@ -175,11 +175,16 @@ class OnePosePlus_model(nn.Module):
 
     def set_gemm_precision(self, name):
         """Arithmetic of the conv / Linear / score GEMMs (not a reference option; every mode meets the same
-        1e-4 parity bar, tests/test_e2e_gpu.py):
+        1e-4 parity bar, tests/test_e2e_gpu.py; fp32 in, fp32 accumulate, fp32 out in every mode):
+          "bf16x3"      default (env OPP_GEMM_PRECISION overrides): operands carried EXACTLY as hi + mid + lo
+                        bf16 triples (24 significant bits, fp32 exponent range), six bf16 MFMAs per product --
+                        not narrower than the reference's fp32, 2.6x the fp32 MFMA peak
           "fp32"        exact fp32 MFMA (bit-for-bit an fmaf chain)
-          "fp16x2"      operands as hi + lo fp16 pairs, three fp16 MFMAs per product, fp32 accumulate
-                        (22-bit operand mantissas); the coarse score GEMM stays fp32
-          "fp16x2_all"  as fp16x2, score GEMM included (default; env OPP_GEMM_PRECISION overrides)
+          "fp16x2"      opt-in fast mode, NARROWER than fp32: operands as hi + lo fp16 pairs (22-bit mantissas,
+                        fp16 exponent range), three fp16 MFMAs per product; the coarse score GEMM stays fp32.
+                        Range guard: a forward whose activations leave the fp16 range is detected on the device
+                        and re-run in bf16x3, and the module stays in bf16x3 from then on (warning)
+          "fp16x2_all"  as fp16x2, score GEMM included
         See include/opp_hip.h `opp_config.gemm_precision`."""
         if name not in GEMM_PRECISIONS:
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
@@ -350,6 +355,14 @@ class OnePosePlus_model(nn.Module):
             t = t.float()
         return t.contiguous()
 
+    def _range_fallback(self, data):
+        """fp16x2 range guard tripped (include/opp_hip.h `opp_set_status_flag`): this forward and all later ones
+        run in bf16x3, which has the full fp32 exponent range."""
+        warnings.warn("onepose_plus_plus_amd: activations left the fp16 range of gemm_precision %r (or the input is not "
+                      "finite); re-running in 'bf16x3' and keeping that arithmetic" % (self.gemm_precision,))
+        self.set_gemm_precision("bf16x3")
+        return self.forward(data)
+
     def forward(self, data):
         """Same contract as the reference forward (OnePosePlusModel.py:96-201); updates `data`."""
         if self.training:
@@ -398,7 +411,9 @@ class OnePosePlus_model(nn.Module):
             mconf = torch.empty(N, dtype=torch.float32, device=device)
             mk_c = torch.empty((N, 2), dtype=torch.float32, device=device)
             mk_3d = torch.empty((N, 3), dtype=torch.float32, device=device)
-            count = torch.zeros(1, dtype=torch.int32, device=device)
+            count = torch.zeros(2, dtype=torch.int32, device=device)    # [M, fp16x2 range-guard flag]
+            guarded = self.gemm_precision in ("fp16x2", "fp16x2_all")
+            _lib.check(lib.opp_set_status_flag(ctx, count.data_ptr() + 4 if guarded else None), "opp_set_status_flag")
             ws_bytes = lib.opp_forward_coarse_workspace_bytes(ctx, H, W, N)
             ws = self._workspace(ws_bytes, device)
             scale_c = float(H) / float(hc)                                               # coarse_matching.py:222
@@ -410,7 +425,9 @@ class OnePosePlus_model(nn.Module):
                 mk_c.data_ptr(), mk_3d.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), stream),
                 "opp_forward_coarse")
             with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
-                M = int(count.item())                                                    # the one D2H sync
+                M, flag = count.tolist()                                                 # the one D2H sync
+            if flag:
+                return self._range_fallback(data)
             b_ids = torch.zeros(M, dtype=torch.int64, device=device)
             data.update({
                 "conf_matrix": conf,
@@ -439,6 +456,8 @@ class OnePosePlus_model(nn.Module):
                 mk_c.data_ptr(), scale_f, qscale.data_ptr() if qscale is not None else None,
                 1 if cfg["loftr_fine"]["enable"] else 0, expec.data_ptr(), mk_f.data_ptr(), fws.data_ptr(),
                 fws.numel(), stream), "opp_fine")
+            if guarded and int(count[1].item()):       # fine-stage GEMMs (fast mode only: one more sync)
+                return self._range_fallback(data)
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             # keep every tensor whose pointer was handed to the stream alive until here
             self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, feat_f)

@@ -10,6 +10,22 @@ E2E_CASES = {
     "e2e_128x128_n300_nomatch": ((128, 128), 300, 0.95, 0, 1, True),   # M == 0 branch
     "e2e_512x512_n2000_thr0": ((512, 512), 2000, 0.0, 0, 1, True),     # BASELINE config 1
     "e2e_512x512_n5000_coarse": ((512, 512), 5000, 0.0, 0, 1, False),  # BASELINE config 2
+    # BASELINE config 3 sizes, full coarse-to-fine: 7000 = the train/val pad size (configs/.../train.yaml:194),
+    # 15000 = the point-count bound max_num_kp3d (sfm_inference_onepose.yaml:26)
+    "e2e_512x512_n7000_thr0": ((512, 512), 7000, 0.0, 0, 1, True),
+    "e2e_512x512_n15000_thr0": ((512, 512), 15000, 0.0, 0, 2, True),
+}
+
+# coarse transformer stage at the headline size on seeded token streams: name -> (L, n_points, seed)
+TRANSFORMER_CASES = {
+    "transformer_l4096_n5000": (4096, 5000, 8),
+}
+
+# end-to-end forward with HUNDREDS of high-confidence matches after backbone + transformer: the coarse descriptor
+# bank is the stored fixture input `bank_c_f16` of <name>.npz (optimised once by gen_golden.py through the oracle,
+# rounded to fp16-representable values); name -> (hw, n_points, n_planted, thr, weight_seed, input_seed)
+HIGHCONF_CASES = {
+    "highconf_512x512_n3000": ((512, 512), 3000, 1500, 0.2, 0, 1),
 }
 
 # planted coarse matcher: name -> (n_points, hw_c, n_planted, noise, seed, thr)

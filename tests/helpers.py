@@ -7,7 +7,7 @@ import torch
 from onepose_plus_plus_amd.config import default_config
 from onepose_plus_plus_amd.synthetic import (make_state_dict, make_inputs,
                                              make_planted_matcher_inputs, make_fine_ids)
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES
+from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -27,6 +27,32 @@ def e2e_setup(name):
     sd = make_state_dict(cfg, wseed)
     data = make_inputs(n, hw, iseed)
     return cfg, sd, data
+
+
+def highconf_setup(name):
+    """-> cfg, sd, data with the optimised coarse bank of the fixture (stored fp16 values) in place."""
+    hw, n, n_planted, thr, wseed, iseed = HIGHCONF_CASES[name]
+    cfg = default_config(thr=thr)
+    sd = make_state_dict(cfg, wseed)
+    data = make_inputs(n, hw, iseed)
+    data["descriptors3d_coarse_db"] = torch.from_numpy(load_golden(name)["bank_c_f16"]).float()
+    return cfg, sd, data
+
+
+def transformer_inputs(L, n, seed):
+    """Seeded O(1) token streams for the coarse transformer stage: tokens2d [1,L,256], bank [1,256,N] (the layout
+    LocalFeatureTransformer.forward takes, transformer.py:133-145)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, L, 256, generator=g), torch.randn(1, 256, n, generator=g)
+
+
+def transformer_digest(f3, f2):
+    """f3 [N,C], f2 [L,C] -> every 16th row + reductions over all rows."""
+    f3, f2 = f3.float().cpu(), f2.float().cpu()
+    return {"f3_rows": f3[::16].contiguous().numpy(), "f2_rows": f2[::16].contiguous().numpy(),
+            "f3_rowsum": f3.sum(1).numpy(), "f2_rowsum": f2.sum(1).numpy(),
+            "f3_rowabs": f3.abs().sum(1).numpy(), "f2_rowabs": f2.abs().sum(1).numpy(),
+            "f3_colsum": f3.sum(0).numpy(), "f2_colsum": f2.sum(0).numpy()}
 
 
 def matcher_setup(name):
@@ -70,6 +96,22 @@ def conf_digest_t(conf):
     else:
         out["conf_sample"] = c[::37, ::41].contiguous().numpy()
     return out
+
+
+def assert_transformer_digest(got, gold, rel, where=""):
+    """every stored row / reduction within `rel` of max(1, |gold|_max) (reductions: scaled by the row length)"""
+    for k, v in gold.items():
+        g = got[k]
+        assert g.shape == v.shape, (where, k, g.shape, v.shape)
+        lim = rel * max(1.0, float(np.abs(v).max())) * (16.0 if k.endswith(("sum", "abs")) else 1.0)
+        err = float(np.abs(g - v).max())
+        assert err <= lim, (where, k, err, lim)
+
+
+def conf_relative_error(got, gold):
+    """max |got - gold| / gold over the matched confidences (gold > 0)"""
+    g, v = to_np(got).astype(np.float64), to_np(gold).astype(np.float64)
+    return float((np.abs(g - v) / np.maximum(v, 1e-30)).max()) if v.size else 0.0
 
 
 def to_np(t):

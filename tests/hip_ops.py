@@ -24,17 +24,36 @@ def pack_h2(w, scaled=True):
     return out, sc
 
 
+def pack_b3(w):
+    """-> bf16x3 pre-split weights (1.5x the floats)"""
+    lib = _lib.load()
+    out = torch.empty(w.numel() // 2 * 3, device="cuda")
+    _lib.check(lib.opp_pack_b3(w.data_ptr(), out.data_ptr(), w.numel(), _s()), "opp_pack_b3")
+    return out
+
+
+def _prec(h2):
+    """test-side selector -> C ABI `prec`: 0 fp32, 1 fp16x2 (scaled split), 2 fp16x2 (unscaled split), 3 bf16x3"""
+    return {0: 0, 1: 1, 2: 1, 3: 2}[h2]
+
+
+def _split(W, h2):
+    if h2 == 3:
+        return pack_b3(W), None
+    if h2:
+        return pack_h2(W, scaled=(h2 == 1))
+    return W, None
+
+
 def linear(A, W, act=0, cfg=-1, h2=0):
     lib = _lib.load()
     A = A.cuda().contiguous()
     W = W.cuda().contiguous()
     M, K = A.shape
     N = W.shape[0]
-    sc = None
-    if h2:
-        W, sc = pack_h2(W, scaled=(h2 == 1))
+    W, sc = _split(W, h2)
     C = torch.full((M, N), float("nan"), device="cuda")
-    _lib.check(lib.opp_linear(A.data_ptr(), M, K, W.data_ptr(), N, act, C.data_ptr(), cfg, 1 if h2 else 0,
+    _lib.check(lib.opp_linear(A.data_ptr(), M, K, W.data_ptr(), N, act, C.data_ptr(), cfg, _prec(h2),
                               sc.data_ptr() if sc is not None else None, _s()), "opp_linear")
     torch.cuda.synchronize()
     return C.cpu()
@@ -46,14 +65,12 @@ def linear_layernorm(A, W, gamma, beta, residual=None, h2=0, in_place=False):
     W = W.cuda().contiguous()
     M, K = A.shape
     N = W.shape[0]
-    sc = None
-    if h2:
-        W, sc = pack_h2(W)
+    W, sc = _split(W, h2)
     g, b = gamma.cuda().contiguous(), beta.cuda().contiguous()
     r = residual.cuda().contiguous() if residual is not None else None
     C = r if (in_place and r is not None) else torch.full((M, N), float("nan"), device="cuda")
     _lib.check(lib.opp_linear_layernorm(A.data_ptr(), M, K, W.data_ptr(), N, g.data_ptr(), b.data_ptr(),
-                                        r.data_ptr() if r is not None else None, C.data_ptr(), 1 if h2 else 0,
+                                        r.data_ptr() if r is not None else None, C.data_ptr(), _prec(h2),
                                         sc.data_ptr() if sc is not None else None, _s()), "opp_linear_layernorm")
     torch.cuda.synchronize()
     return C.cpu()
@@ -88,9 +105,7 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
         sd[:cout] = scale.cuda()
     _lib.check(lib.opp_pack_conv_weight(wd.data_ptr(), sd.data_ptr() if sd is not None else None, cout, cin, ks,
                                         cout_p, cin_p, wp.data_ptr(), _s()), "pack")
-    sc = None
-    if h2:
-        wp, sc = pack_h2(wp, scaled=(h2 == 1))
+    wp, sc = _split(wp, h2)
     bd = None
     if bias is not None:
         bd = torch.zeros(cout_p, device="cuda")
@@ -101,7 +116,7 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
     y = torch.full((Ho, Wo, cout_p), float("nan"), device="cuda")
     _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin_p, wp.data_ptr(), bd.data_ptr() if bd is not None else None,
                                    cout_p, ks, stride, rd.data_ptr() if rd is not None else None, res_mode, act,
-                                   y.data_ptr(), cfg, 1 if h2 else 0, sc.data_ptr() if sc is not None else None, _s()),
+                                   y.data_ptr(), cfg, _prec(h2), sc.data_ptr() if sc is not None else None, _s()),
                "conv2d")
     torch.cuda.synchronize()
     pad_part = y[:, :, cout:]
@@ -120,7 +135,7 @@ def layer_norm(x, g, b, res=None):
     return out.cpu()
 
 
-PRECISIONS = ("fp32", "fp16x2", "fp16x2_all")
+PRECISIONS = ("bf16x3", "fp32", "fp16x2", "fp16x2_all")
 
 
 def make_model(cfg, sd, precision=None):

@@ -6,12 +6,12 @@ import pytest
 import torch
 
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES
+from tests.golden.cases import E2E_CASES, HIGHCONF_CASES
 
 pytestmark = pytest.mark.gpu
 
 
-PRECISIONS = ["fp32", "fp16x2", "fp16x2_all"]     # every GEMM arithmetic meets the same parity bar
+PRECISIONS = ["bf16x3", "fp32", "fp16x2", "fp16x2_all"]     # every GEMM arithmetic meets the same parity bar
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -37,6 +37,26 @@ def test_e2e_vs_golden(name, precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("name", list(HIGHCONF_CASES))
+def test_e2e_high_confidence_vs_golden(name, precision):
+    """Full coarse-to-fine forward whose coarse bank was optimised (through the oracle) so that ~1500 pairs reach
+    conf > 0.5 (up to 0.999) AFTER backbone + positional encodings + 6 transformer layers: every GEMM arithmetic must
+    reproduce the reference's indices bit-exactly and its confidences / fine offsets within 1e-4 where the bar
+    actually bites; the relative error is reported too."""
+    from tests import hip_ops as ops
+    cfg, sd, data = H.highconf_setup(name)
+    out = ops.run_model(ops.make_model(cfg, sd, precision), data)
+    gold = H.load_golden(name)
+    assert len(gold["mconf"]) > 1000 and (gold["mconf"] > 0.5).sum() > 1000
+    H.assert_match_outputs(out, gold, where=name)
+    rel = H.conf_relative_error(out["mconf"], gold["mconf"])
+    absd = float(np.abs(H.to_np(out["mconf"]) - gold["mconf"]).max())
+    print("%s [%s]: M %d, mconf max abs err %.2e, max rel err %.2e, expec_f max abs err %.2e" %
+          (name, precision, len(gold["mconf"]), absd, rel, float(np.abs(H.to_np(out["expec_f"]) - gold["expec_f"]).max())))
+    assert rel < 1e-3
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_e2e_vs_oracle_and_determinism(precision):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
@@ -57,7 +77,7 @@ def test_e2e_vs_oracle_and_determinism(precision):
         assert torch.equal(v, data[k]), k
 
 
-@pytest.mark.parametrize("n,precision", [(5000, "fp32"), (5000, "fp16x2"), (5000, "fp16x2_all"), (15000, "fp32"), (15000, "fp16x2_all")])
+@pytest.mark.parametrize("n,precision", [(5000, "bf16x3"), (5000, "fp32"), (5000, "fp16x2"), (5000, "fp16x2_all"), (15000, "bf16x3"), (15000, "fp32"), (15000, "fp16x2_all")])
 def test_full_size_properties(n, precision):
     """BASELINE sizes: properties that hold for any input (no oracle needed)."""
     from tests import hip_ops as ops

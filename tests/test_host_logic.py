@@ -122,9 +122,9 @@ def test_gemm_precision_selector(monkeypatch):
     import pickle
     from onepose_plus_plus_amd import model as M
     m = OnePosePlus_model(default_config())
-    assert m.gemm_precision == M.DEFAULT_GEMM_PRECISION == "fp16x2_all"
-    assert [m.set_gemm_precision(p)._c_config().gemm_precision for p in ("fp32", "fp16x2", "fp16x2_all")] == [0, 1, 2]
-    assert pickle.loads(pickle.dumps(m)).gemm_precision == "fp16x2_all"          # travels to Ray-style workers
+    assert m.gemm_precision == M.DEFAULT_GEMM_PRECISION == "bf16x3"        # the default is not narrower than fp32
+    assert [m.set_gemm_precision(p)._c_config().gemm_precision for p in ("fp32", "fp16x2", "fp16x2_all", "bf16x3")] == [0, 1, 2, 3]
+    assert pickle.loads(pickle.dumps(m)).gemm_precision == "bf16x3"              # travels to Ray-style workers
     with pytest.raises(ValueError):
         m.set_gemm_precision("bf16")
     monkeypatch.setenv("OPP_GEMM_PRECISION", "fp32")

@@ -42,6 +42,73 @@ def test_linear_fp16x2(M, K, N, cfg):
     assert (err <= 2e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (77, 256, 96), (50, 64, 81),
+                                   (33, 96, 7), (515, 1152, 130), (1000, 64, 128)])
+@pytest.mark.parametrize("cfg", [-1, 1, 2, 25, 26])
+def test_linear_bf16x3(M, K, N, cfg):
+    """bf16x3-split operands (exact hi + mid + lo bf16, six bf16 MFMAs, fp32 accumulate): the default arithmetic."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    ref = (A.double() @ W.double().T).float()
+    got = ops.linear(A, W, 0, cfg, h2=3)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert (err <= 1e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
+    for bad in (0, 20, 22, 27, 28, 3):      # tiles without a bf16x3 build are refused, never silently another arithmetic
+        with pytest.raises(Exception):
+            ops.linear(A, W, 0, bad, h2=3)
+
+
+def test_linear_bf16x3_identity_layout():
+    """A = I with an asymmetric W: the six products reproduce W^T EXACTLY (the split is an error-free encoding)."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    W = torch.randn(128, 64, generator=g) * torch.exp2(torch.randint(-30, 30, (128, 1), generator=g).float())
+    got = ops.linear(torch.eye(64), W, 0, -1, h2=3)
+    assert torch.equal(got, W.T.contiguous())
+
+
+@pytest.mark.parametrize("sa,sw", [(1.0, 1.0), (1e5, 0.02), (1e-6, 1.0), (3e4, 300.0), (1e-6, 1e-6), (1e10, 1e-10)])
+def test_bf16x3_not_narrower_than_fp32(sa, sw):
+    """Error of the bf16x3 GEMM vs fp64, relative to sum|a||w|, against the exact-fp32 MFMA GEMM of the same inputs:
+    no larger (both are fp32-accumulation round-off), at ANY operand magnitude -- activations of 1e5 and 1e-6
+    included, where the fp16x2 fast mode overflows / loses relative precision."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(256, 1152, generator=g) * sa
+    W = torch.randn(192, 1152, generator=g) * sw
+    ref = A.double() @ W.double().T
+    bound = A.abs().double() @ W.abs().double().T
+    e_b3 = ((ops.linear(A, W, 0, -1, h2=3).double() - ref).abs() / bound)
+    e_f32 = ((ops.linear(A, W, 0, -1, h2=0).double() - ref).abs() / bound)
+    print("bf16x3 rel err max %.3e mean %.3e | fp32 MFMA max %.3e mean %.3e" %
+          (e_b3.max(), e_b3.mean(), e_f32.max(), e_f32.mean()))
+    assert e_b3.max() <= 1.25 * e_f32.max() + 2.0 ** -26, (float(e_b3.max()), float(e_f32.max()))
+    assert e_b3.mean() <= 1.25 * e_f32.mean() + 2.0 ** -28
+    if sa == 1e-6 and sw == 1.0:    # what the exactness buys: the fast mode is absolute-error limited down there
+        e_h2 = ((ops.linear(A, W, 0, -1, h2=1).double() - ref).abs() / bound).max().item()
+        assert e_h2 > 100 * e_b3.max().item(), (e_h2, float(e_b3.max()))
+
+
+@pytest.mark.parametrize("mag", [1e-30, 1e-5, 1.0, 700.0, 1e20])
+def test_pack_b3_bit_exact_vs_oracle(mag):
+    """`opp_pack_b3` (operand pre-split for the bf16x3 GEMMs): byte-exact against oracle/bf16x3_oracle.py."""
+    import numpy as np
+    from oracle import bf16x3_oracle as X
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(192, 1152, generator=g) * mag
+    w[3, 5] = 0.0
+    w[7, :8] = torch.tensor([mag * 2.0 ** -12, -mag * 2.0 ** -20, mag * (1 + 2.0 ** -8), -mag * (1 + 3 * 2.0 ** -8), mag, -mag,
+                             mag / 3, -mag / 7])
+    out = ops.pack_b3(w.cuda())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint16).reshape(-1, 24)
+    assert np.array_equal(got, X.split_packed(w.numpy()))
+
+
 @pytest.mark.parametrize("sa,sw", [(1.0, 0.02), (1.0, 1e-4), (1.0, 300.0), (30.0, 1e-6), (0.05, 0.02)])
 def test_linear_fp16x2_weight_magnitudes(sa, sw):
     """The per-matrix power-of-two weight scale keeps the fp16 lo halves normal: accuracy does not depend on
@@ -134,6 +201,27 @@ def test_conv_fp16x2(cin, cout, ks, stride, H, W, cfg):
         ops.conv2d(x, w, scale, bias, stride, res, 1, 1, 3, h2=1)
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
+@pytest.mark.parametrize("cfg", [-1, 1, 2, 25, 26])
+def test_conv_bf16x3(cin, cout, ks, stride, H, W, cfg):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+    res = torch.randn(1, cout, Ho, Wo, generator=g)
+    ref = F.conv2d(x.double(), (w * scale.view(-1, 1, 1, 1)).double(), bias.double(), stride, ks // 2) + res.double()
+    ref = F.relu(ref).float()
+    got, pad_max = ops.conv2d(x, w, scale, bias, stride, res, 1, 1, cfg, h2=3)
+    assert pad_max == 0.0
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(Exception):          # the 224-column tiles have no bf16x3 build: refused, not silently fp32
+        ops.conv2d(x, w, scale, bias, stride, res, 1, 1, 3, h2=3)
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(196, 256, 12, 16), (128, 196, 20, 12)])
 def test_conv1x1_bilinear_residual(cin, cout, H, W):
     """lateral 1x1 conv + align_corners=True x2 upsample of the coarser map (resnet.py:151-157)."""
@@ -171,7 +259,7 @@ def test_layernorm(C):
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 256, 256), (9096, 512, 256), (64, 256, 256), (77, 128, 128), (1000, 256, 128)])
-@pytest.mark.parametrize("h2", [0, 1])
+@pytest.mark.parametrize("h2", [0, 1, 3])
 @pytest.mark.parametrize("with_res", [False, True])
 def test_linear_layernorm_fused(M, K, N, h2, with_res):
     """GEMM with the LayerNorm (+ residual) of LoFTREncoderLayer fused into its epilogue vs fp64."""

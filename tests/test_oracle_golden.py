@@ -8,12 +8,12 @@ import torch
 from oracle import onepose_oracle as O
 from oracle.refload import reference_available, load_reference_model_class
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES
+from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES
 
 SMALL_E2E = [n for n in E2E_CASES if "512" not in n]
 
 
-@pytest.mark.parametrize("name", SMALL_E2E + ["e2e_512x512_n2000_thr0"])
+@pytest.mark.parametrize("name", SMALL_E2E + ["e2e_512x512_n2000_thr0", "e2e_512x512_n7000_thr0", "e2e_512x512_n15000_thr0"])
 def test_oracle_e2e_vs_golden(name):
     cfg, sd, data = H.e2e_setup(name)
     O.forward(sd, data, cfg)
@@ -42,6 +42,32 @@ def test_oracle_stages_vs_golden():
         f3, f2 = O.local_feature_transformer(sd, "loftr_coarse", cfg["loftr_coarse"], bank, tok)
         assert np.abs(f3.numpy() - gold["f3"]).max() < 5e-5
         assert np.abs(f2.numpy() - gold["f2"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("name", list(TRANSFORMER_CASES))
+def test_oracle_transformer_vs_golden(name):
+    """loftr_coarse at the headline size (L = 4096, N = 5000) on seeded token streams."""
+    L, n, seed = TRANSFORMER_CASES[name]
+    cfg = H.default_config()
+    sd = H.make_state_dict(cfg, 0)
+    tokens2d, bank = H.transformer_inputs(L, n, seed)
+    with torch.no_grad():
+        f3, f2 = O.local_feature_transformer(sd, "loftr_coarse", cfg["loftr_coarse"], bank, tokens2d)
+    H.assert_transformer_digest(H.transformer_digest(f3[0], f2[0]), H.load_golden(name), rel=2e-5, where=name)
+
+
+@pytest.mark.parametrize("name", list(HIGHCONF_CASES))
+def test_oracle_highconf_vs_golden(name):
+    """Whole forward with > 1400 matches of confidence > 0.5 (up to 0.999) after backbone + transformer: here the
+    1e-4 bar on confidences bites end to end; relative error reported as well."""
+    cfg, sd, data = H.highconf_setup(name)
+    O.forward(sd, data, cfg)
+    gold = H.load_golden(name)
+    assert len(gold["mconf"]) > 1000 and (gold["mconf"] > 0.5).sum() > 1000 and gold["mconf"].max() > 0.99
+    H.assert_match_outputs(data, gold, tol_conf=2e-5, tol_off=5e-5, tol_px=2e-4, where=name)
+    rel = H.conf_relative_error(data["mconf"], gold["mconf"])
+    print("%s: oracle vs reference mconf max rel err %.2e" % (name, rel))
+    assert rel < 1e-4
 
 
 @pytest.mark.parametrize("name", list(MATCHER_CASES))

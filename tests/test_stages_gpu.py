@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from tests import helpers as H
-from tests.golden.cases import MATCHER_CASES, FINE_CASES
+from tests.golden.cases import MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -14,7 +14,7 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
 
 
-@pytest.fixture(scope="module", params=["fp32", "fp16x2", "fp16x2_all"])
+@pytest.fixture(scope="module", params=["bf16x3", "fp32", "fp16x2", "fp16x2_all"])
 def small(request):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
@@ -96,7 +96,7 @@ def test_fine_vs_golden(small, name):
                            where=name)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16x2_all"])
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "fp16x2_all"])
 def test_matcher_exact_ties_follow_reference_rules(precision):
     """Duplicated image cells (tie inside a row -> first column wins) and duplicated 3D points
     (both rows are reported with the same cell), coarse_matching.py:158-172 / quirk q9."""
@@ -153,3 +153,19 @@ def test_tiny_shapes_vs_oracle(hw, n):
     if len(ref["mconf"]):
         assert (out["expec_f"].cpu() - ref["expec_f"]).abs().max() < 1e-4
         assert (out["mkpts_query_f"].cpu() - ref["mkpts_query_f"]).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32", "fp16x2"])
+@pytest.mark.parametrize("name", list(TRANSFORMER_CASES))
+def test_transformer_stage_full_size_vs_golden(name, precision):
+    """loftr_coarse alone at L = 4096 image tokens x N = 5000 points against the reference's outputs."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    L, n, seed = TRANSFORMER_CASES[name]
+    cfg = default_config()
+    model = ops.make_model(cfg, make_state_dict(cfg, 0), precision)
+    tokens2d, bank = H.transformer_inputs(L, n, seed)
+    x = torch.cat([tokens2d[0], bank[0].t().contiguous()], 0)           # [L + N, C]: image tokens first
+    y = ops.transformer(model, 0, x, 1, L, n)
+    H.assert_transformer_digest(H.transformer_digest(y[L:], y[:L]), H.load_golden(name), rel=5e-5, where=name)

@@ -53,12 +53,25 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
+def split_w(lib, w, cfgs, prec, s):
+    """pre-split the weight operand for `prec`; keep only tile configs built for it (+ the automatic choice)"""
+    if prec == 1:
+        w2 = torch.empty_like(w)
+        _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack_h2")
+        return w2, sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
+    if prec == 2:
+        w2 = torch.empty(w.numel() // 2 * 3, device="cuda")
+        _lib.check(lib.opp_pack_b3(w.data_ptr(), w2.data_ptr(), w.numel(), s), "pack_b3")
+        return w2, sorted(set([c for c in cfgs if c in (1, 2, 25, 26, 30)] + [-1]))
+    return w, cfgs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--cfgs", default=None, help="comma list: only these tile configs")
-    ap.add_argument("--h2", type=int, default=0, help="1: fp16x2 split kernels (cfgs 0,1,2,10,11 only)")
+    ap.add_argument("--prec", type=int, default=2, help="operand arithmetic: 0 fp32, 1 fp16x2, 2 bf16x3 (default)")
     args = ap.parse_args()
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
@@ -73,11 +86,7 @@ def main():
         bias = torch.randn(cop, device="cuda")
         alg = 2.0 * Ho * Wo * cout * ks * ks * cin
         padf = 2.0 * Ho * Wo * cop * ks * ks * cip
-        if args.h2:
-            w2 = torch.empty_like(w)
-            _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack_h2")
-            w = w2
-            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
+        w, cfgs = split_w(lib, w, cfgs, args.prec, s)
         if args.cfgs:
             cfgs = [int(c) for c in args.cfgs.split(",")]
         for cfg in cfgs:
@@ -88,7 +97,7 @@ def main():
 
             def fn():
                 _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cip, w.data_ptr(), bias.data_ptr(), cop, ks, stride,
-                                               None, 0, 1, y.data_ptr(), cfg, args.h2, None, s), "conv")
+                                               None, 0, 1, y.data_ptr(), cfg, args.prec, None, s), "conv")
             try:
                 us = timeit(fn, args.iters)
                 print("%-32s cfg%d  %8.1f us  alg %6.1f TF  padded %6.1f TF" % (name, cfg, us, alg / us / 1e6, padf / us / 1e6), flush=True)
@@ -100,18 +109,17 @@ def main():
         A = torch.randn(M, K, device="cuda")
         Wt = torch.randn(N, K, device="cuda")
         C = torch.empty(M, N, device="cuda")
-        if args.h2:
-            w2 = torch.empty_like(Wt)
-            _lib.check(lib.opp_pack_h2(Wt.data_ptr(), w2.data_ptr(), Wt.numel(), None, s), "pack_h2")
-            Wt = w2
-            cfgs = sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
+        Wt, cfgs = split_w(lib, Wt, cfgs, args.prec, s)
         if args.cfgs:
             cfgs = [int(c) for c in args.cfgs.split(",")]
         for cfg in cfgs:
             def fn():
-                _lib.check(lib.opp_linear(A.data_ptr(), M, K, Wt.data_ptr(), N, 0, C.data_ptr(), cfg, args.h2, None, s), "linear")
-            us = timeit(fn, args.iters)
-            print("%-32s cfg%d  %8.1f us  %6.1f TF" % (name, cfg, us, 2.0 * M * K * N / us / 1e6), flush=True)
+                _lib.check(lib.opp_linear(A.data_ptr(), M, K, Wt.data_ptr(), N, 0, C.data_ptr(), cfg, args.prec, None, s), "linear")
+            try:
+                us = timeit(fn, args.iters)
+                print("%-32s cfg%d  %8.1f us  %6.1f TF" % (name, cfg, us, 2.0 * M * K * N / us / 1e6), flush=True)
+            except Exception as e:
+                print("%-32s cfg%d  FAILED %s" % (name, cfg, e), flush=True)
 
 
 if __name__ == "__main__":

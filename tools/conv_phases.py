@@ -1,5 +1,6 @@
 """Phase breakdown (prologue / K loop / epilogue, shader clocks) of the conv kernel from in-kernel time stamps.
-    python tools/conv_phases.py [--h2 1]"""
+    python -m onepose_plus_plus_amd.build --tuning
+    OPP_HIP_LIB=onepose_plus_plus_amd/libopp_hip_tuning.so python tools/conv_phases.py [--prec 2]"""
 import argparse
 import os
 import sys
@@ -16,26 +17,33 @@ CASES = [("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1), ("l1_out2a 3x3 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--h2", type=int, default=1)
+    ap.add_argument("--prec", type=int, default=2, help="0 fp32, 1 fp16x2, 2 bf16x3")
     args = ap.parse_args()
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
     for name, H, W, cin, cout, ks, stride in CASES:
         x = torch.randn(H, W, cin, device="cuda")
         w = torch.randn(cout, ks * ks * cin, device="cuda") * 0.02
-        if args.h2:
+        if args.prec == 1:
             w2 = torch.empty_like(w)
             _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack")
             w = w2
+        elif args.prec == 2:
+            w2 = torch.empty(w.numel() // 2 * 3, device="cuda")
+            _lib.check(lib.opp_pack_b3(w.data_ptr(), w2.data_ptr(), w.numel(), s), "pack")
+            w = w2
         y = torch.empty(H // stride, W // stride, cout, device="cuda")
         bias = torch.randn(cout, device="cuda")
-        for cfg, bm, bn, waves in ((120, 256, 128, 8), (121, 128, 128, 4)) + (((191, 256, 128, 8), (192, 256, 128, 8), (193, 256, 128, 8)) if args.h2 else ()):
+        variants = {0: ((120, 256, 128, 8), (121, 128, 128, 4), (122, 128, 128, 8)),
+                    1: ((120, 256, 128, 8), (121, 128, 128, 4), (122, 128, 128, 8), (191, 256, 128, 8), (192, 256, 128, 8), (193, 256, 128, 8)),
+                    2: ((122, 128, 128, 8), (291, 128, 128, 8), (292, 128, 128, 8), (293, 128, 128, 8), (294, 128, 128, 8), (295, 128, 128, 8))}[args.prec]
+        for cfg, bm, bn, waves in variants:
             nb = -(-(H // stride) * (W // stride) // bm) * -(-cout // bn)
             ts = torch.zeros(nb * waves * 4, dtype=torch.int64, device="cuda")
             _lib.check(lib.opp_debug_timestamps(ts.data_ptr()), "ts")
             for _ in range(3):
                 _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, w.data_ptr(), bias.data_ptr(), cout, ks, stride,
-                                               None, 0, 1, y.data_ptr(), cfg, args.h2, None, s), "conv")
+                                               None, 0, 1, y.data_ptr(), cfg, args.prec, None, s), "conv")
             torch.cuda.synchronize()
             t = ts.view(nb, waves, 4).double().cpu()
             pro, loop, epi = (t[..., 1] - t[..., 0]), (t[..., 2] - t[..., 1]), (t[..., 3] - t[..., 2])
