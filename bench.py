@@ -56,6 +56,8 @@ PREC_ID = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 1, "bf16x3": 2}
 # 0 = dense GEMM, 2 = coarse score GEMM with the fused dual-softmax statistics.  Only symbols the model actually
 # launches for the arithmetic in use show up (launches > 0).
 GEMM_SYMBOLS = [
+    (20, 1, "256, 128, 4, 2, true", "implicit-GEMM conv, 256x128 tile, 8 waves"),
+    (22, 1, "128, 256, 2, 4, true", "implicit-GEMM conv, 128x256 tile, 8 waves"),
     (25, 1, "128, 128, 4, 2, true", "implicit-GEMM conv, 128x128 tile, 8 waves"),
     (26, 1, "64, 128, 2, 4, true", "implicit-GEMM conv, 64x128 tile, 8 waves"),
     (11, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves, prefetch depth 4"),
@@ -63,12 +65,15 @@ GEMM_SYMBOLS = [
     (0, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves"),
     (1, 1, "64, 128, 2, 2, true", "implicit-GEMM conv, 64x128 tile, 4 waves"),
     (2, 1, "64, 64, 2, 2, true", "implicit-GEMM conv, 64x64 tile, 4 waves"),
+    (20, 0, "256, 128, 4, 2, false", "dense GEMM, 256x128 tile, 8 waves"),
+    (22, 0, "128, 256, 2, 4, false", "dense GEMM, 128x256 tile, 8 waves"),
     (25, 0, "128, 128, 4, 2, false", "dense GEMM (QKV, mlp.0, stem), 128x128 tile, 8 waves"),
     (0, 0, "128, 128, 2, 2, false", "dense GEMM (QKV, mlp.0, stem), 128x128 tile, 4 waves"),
     (26, 0, "64, 128, 2, 4, false", "dense GEMM, 64x128 tile, 8 waves"),
     (1, 0, "64, 128, 2, 2, false", "dense GEMM, 64x128 tile, 4 waves"),
     (2, 0, "64, 64, 2, 2, false", "dense GEMM, 64x64 tile, 4 waves"),
     (30, 0, "64, 256, 2, 4, false", "dense GEMM + fused LayerNorm (merge, mlp.2), 64x256 tile, 8 waves"),
+    (20, 2, "256, 128, 4, 2, false", "coarse score GEMM + fused dual-softmax statistics, 256x128 tile, 8 waves"),
     (25, 2, "128, 128, 4, 2, false", "coarse score GEMM + fused dual-softmax statistics, 128x128 tile, 8 waves"),
     (0, 2, "128, 128, 2, 2, false", "coarse score GEMM + fused dual-softmax statistics, 128x128 tile, 4 waves"),
 ]

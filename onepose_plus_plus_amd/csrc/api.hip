@@ -802,8 +802,11 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   g.n_store = L;
   g.out_mul = 1.0f / (float)C;
   g.out_div = (float)((double)c->cfg.match_temperature + 1e-4);
+  // tile rows of the score GEMM: 128 (config 0 / 25); bf16x3 with enough rows: the 256x128 8-wave tile (config 20)
+  const int score_cfg = sprec == OPP_PREC_BF16X3 ? (n >= 512 ? 20 : 25) : 0;
+  const int score_bm = score_cfg == 20 ? 256 : 128;
   {  // dual-softmax (max, sum exp) partials fused into the epilogue: [n][tn] x2, [tm][L] x2
-    const size_t tn = opp_cdiv(L, 128), tm = opp_cdiv(n, 128);
+    const size_t tn = opp_cdiv(L, 128), tm = opp_cdiv(n, score_bm);
     g.stat_rowmax = stats;
     g.stat_rowsum = g.stat_rowmax + (size_t)n * tn;
     g.stat_colmax = g.stat_rowsum + (size_t)n * tn;
@@ -816,9 +819,8 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
     g.ldw = (int)split_floats((size_t)C, sprec);
     g.prec = sprec;
   }
-  // 128x128 tiles: the partial layout above assumes them (bf16x3: the 8-wave variant)
-  OPP_TRY(opp_gemm_launch_cfg(g, sprec == OPP_PREC_BF16X3 ? 25 : 0, s));
-  return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, stats, scratch, i_ids, j_ids,
+  OPP_TRY(opp_gemm_launch_cfg(g, score_cfg, s));   // the partial layout above assumes this tile shape
+  return opp_dual_softmax_select(conf, n, L, wc, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, stats, score_bm, scratch, i_ids, j_ids,
                                  mconf, mkpts_c, mkpts_3d, count, s);
 }
 
@@ -927,6 +929,8 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
     return OPP_ERR_WORKSPACE;
   }
   float* f3 = X + (size_t)M * WW * C;
+  // whole fine stage as one profiled span; algorithmic bytes: windows + point descriptors gathered, outputs written
+  OppProfScope prof(OPP_PROF_FINE, s, (double)M * ((double)(WW + 1) * C * 4.0 + 5 * 4.0));
   OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
   if (run_transformer)
     OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg)));

@@ -435,9 +435,10 @@ size_t opp_coarse_match_scratch_floats(int N, int L) {
 
 // S (in: similarity, out: confidence matrix) [N][L].  Outputs have capacity N.
 int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts, float base_scale,
-                            const float* qscale, const float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
+                            const float* qscale, const float* stats, int stats_bm, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
                             float* mkpts_3d, int* count, hipStream_t stream) {
   OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0, "coarse match: bad sizes N=%d L=%d wc=%d", N, L, wc);
+  OPP_CHECK_ARG(!stats || stats_bm == 128 || stats_bm == 256, "coarse match: statistics come from 128- or 256-row GEMM tiles");
   const int chunks = opp_cdiv(N, 128);
   const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
   float* rmax = scratch;
@@ -453,7 +454,7 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   dim3 rgrid(opp_cdiv(N, 4)), cgrid(opp_cdiv(L, 256), chunks), lgrid(opp_cdiv(L, 256));
 
   if (stats) {   // (max, sum exp) partials already produced by the score GEMM epilogue
-    const int tn = opp_cdiv(L, 128), tm = opp_cdiv(N, 128);
+    const int tn = opp_cdiv(L, 128), tm = opp_cdiv(N, stats_bm);   // score GEMM tiles: stats_bm rows x 128 columns
     const float* rpm = stats;
     const float* rps = rpm + (size_t)N * tn;
     const float* cpm = rps + (size_t)N * tn;

@@ -933,7 +933,7 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // must divide over the workgroup; its 4-wave 128x128 tile would not fit the register file)
   constexpr bool ok = PREC == OPP_PREC_FP32 ||
                       ((BN == 128 || BN == 64 || BN == 256) &&
-                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 32 && NT <= 512)));
+                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64 && NT <= 512)));
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
@@ -1060,6 +1060,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     OPP_CHECK_ARG(g.ksplit % 32 == 0 && (g.ksplit >= g.K || g.A1), "gemm: bad ksplit");
     OPP_CHECK_ARG(g.res_mode != OPP_RES_BILINEAR2X, "gemm: bilinear residual needs conv mode");
   }
+  const bool auto_cfg = cfg < 0;
   if (cfg < 0) {
     // Tile choice from the MI355X micro-bench (tools/conv_bench.py; 256 CUs x 4 SIMDs).  The
     // 196(->224)-channel stages run as two column tiles (128 + 96 real columns): measured 4-12 %
@@ -1076,23 +1077,49 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     // fp32, 128-column outputs of the 256x256-pixel layers: the 8-wave 128x128 tile (two waves per SIMD cover the
     // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
     if (!split && t0 >= 384 && g.n_store <= 128) cfg = 25;
-    if (split) {
-      // fp16x2 / bf16x3: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Policy:
-      // 128x128 (fp16x2 73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel --
+    if (g.prec == OPP_PREC_FP16X2) {
+      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Policy:
+      // 128x128 (73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel --
       // fits on the CU) wherever it still gives ~a workgroup per CU, else 64x128, else the 4-wave 64x64 tile.
-      // The 256x128 / 128x256 fp16x2 tiles (110 KB LDS) are 2-5 % faster for a kernel running alone on the two
+      // The 256x128 / 128x256 tiles (110 KB LDS) are 2-5 % faster for a kernel running alone on the two
       // largest layers but cost 2.3 % of the throughput with three forwards in flight (no co-residency).
       if (t0 >= 200) cfg = 25;          // 128x128 on 8 waves (32x64 per wave)
       else if (t1 >= 512) cfg = 26;     // 64x128 on 8 waves
       else cfg = 2;
+    } else if (g.prec == OPP_PREC_BF16X3) {
+      // bf16x3: the operand tiles are 1.5x larger (208 B per row and chunk), so the 128x128 tile already owns a CU
+      // (106 KB LDS) and the grid runs in whole rounds of <= 256 workgroups: pick the tile with the smallest
+      // estimated time = rounds x (K chunks x cycles per chunk + prologue / epilogue), constants from the MI355X
+      // micro-bench (tools/conv_bench.py --prec 2): the 256x128 / 128x256 8-wave tiles (160 KB LDS, 64x64 per wave)
+      // win wherever they still fill the chip in one round (256x256-pixel layers, QKV), 128x128 on the 128x128-pixel
+      // layers, 64x128 (80 KB, two workgroups per CU) / 64x64 below that.
+      // wpc = workgroups of this tile that share a CU (by LDS); co-resident workgroups share the matrix pipes, so a
+      // chunk then costs wpc x the stand-alone time.
+      struct Cand { int cfg, bm, bn, wpc, chunk, fixed; };
+      static const Cand cands[] = {{22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
+                                   {25, 128, 128, 1, 2600, 13000}, {26, 64, 128, 2, 1400, 11000},
+                                   {2, 64, 64, 3, 1000, 9000}};
+      const long long nk = g.K / 32, cus = 256;
+      long long best = -1;
+      for (const Cand& c : cands) {
+        if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
+        const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
+        const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
+        long long est = full * (nk * c.chunk * c.wpc + c.fixed);
+        if (rem > 0) est += nk * c.chunk * ((rem + cus - 1) / cus) + c.fixed;
+        if (best < 0 || est < best) {
+          best = est;
+          cfg = c.cfg;
+        }
+      }
     }
   }
   // (the statistics scratch sits behind the staged C tile in the operand LDS: 4-wave tile for fp32 / fp16x2,
   // 8-wave tile for bf16x3, whose operand buffers are larger)
-  OPP_CHECK_ARG(g.stat_rowmax == nullptr || (g.prec == OPP_PREC_BF16X3 ? cfg == 25 : cfg == 0),
-                "gemm: fused softmax statistics need the 128x128 tile (config 0; bf16x3: config 25)");
+  OPP_CHECK_ARG(g.stat_rowmax == nullptr || (g.prec == OPP_PREC_BF16X3 ? (cfg == 25 || cfg == 20) : cfg == 0),
+                "gemm: fused softmax statistics need the 128x128 tile (config 0; bf16x3: config 25, or 20 = 256x128)");
   if (g.ln_gamma != nullptr) {
-    if (cfg < 0 || (cfg != 30 && cfg != 26)) cfg = g.n_store == 256 ? 30 : 26;
+    if (auto_cfg || (cfg != 30 && cfg != 26)) cfg = g.n_store == 256 ? 30 : 26;   // the tile must span the row
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     OPP_CHECK_ARG(g.ln_beta && ((cfg == 30 && g.n_store == 256) || (cfg == 26 && g.n_store == 128)) && g.N == g.n_store && !g.bias &&
                       g.act == OPP_ACT_NONE && g.res_mode == OPP_RES_NONE && g.ldc % 4 == 0 && al(g.C) && al(g.ln_gamma) &&

@@ -59,7 +59,7 @@ int opp_bank_transpose(const float* bank, int n, int C, float* tokens, int ldo, 
 size_t opp_coarse_match_scratch_floats(int N, int L);
 size_t opp_coarse_match_stats_floats(int N, int L);
 int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts,
-                            float base_scale, const float* qscale, const float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                            float base_scale, const float* qscale, const float* stats, int stats_bm, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
                             float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);
 // fine.hip
 int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,

@@ -62,7 +62,7 @@ def split_w(lib, w, cfgs, prec, s):
     if prec == 2:
         w2 = torch.empty(w.numel() // 2 * 3, device="cuda")
         _lib.check(lib.opp_pack_b3(w.data_ptr(), w2.data_ptr(), w.numel(), s), "pack_b3")
-        return w2, sorted(set([c for c in cfgs if c in (1, 2, 25, 26, 30)] + [-1]))
+        return w2, sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 20, 22, 25, 26, 30)] + [-1]))
     return w, cfgs
 
 
