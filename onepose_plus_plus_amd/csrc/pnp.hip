@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-  if (lane == 0) score[h] = cnt;
+  if (lane == 0) score[h] = valid[h] ? cnt : -1;   // -1: degenerate sample, never the best
 }
 
 // single workgroup: best hypothesis, Gauss-Newton refinement on its inliers, final inlier mask
@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
   }
   const int best_score = s_best[0], best_h = s_idx[0];
   if (tid == 0) {
-    s_fail = best_score < 4 ? 1 : 0;
+    // fail only without any valid hypothesis (fewer than 4 matches, degenerate geometry): the reference's cv2.error
+    // branch.  A best hypothesis with fewer than 4 inliers is still returned (state True, its few inliers), like
+    // cv2.solvePnPRansac, which then reports success with an empty / tiny inlier set (metric_utils.py:194-196)
+    s_fail = best_score < 0 ? 1 : 0;
     if (!s_fail) {
       for (int k = 0; k < 9; ++k) s_pose.R[k] = hyp[(size_t)best_h * 12 + k];
       for (int k = 0; k < 3; ++k) s_pose.t[k] = hyp[(size_t)best_h * 12 + 9 + k];

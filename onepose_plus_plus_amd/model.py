@@ -129,6 +129,11 @@ def _validate_config(cfg):
                 raise NotImplementedError
         if t["redraw_interval"] is not None:
             assert t["redraw_interval"] % 2 == 0
+    ws = cfg["loftr_fine"]["window_size"]
+    if int(ws) != ws or ws < 3 or ws % 2 == 0 or ws * ws > 64:
+        # the expectation grid divides by (W - 1) (fine_matching.py:87 via kornia create_meshgrid) and the window
+        # centre is W // 2: W = 1 gives NaN offsets upstream, an even W has no centre cell
+        raise ValueError("loftr_fine.window_size must be an odd integer in [3, 7], got %r" % (ws,))
     cm = cfg["coarse_matching"]
     if cm["type"] != "dual-softmax":                   # coarse_matching.py:63-66
         raise NotImplementedError()
@@ -320,22 +325,35 @@ class OnePosePlus_model(nn.Module):
         """Encoded 3D-point tokens [N, C] of the current object.  They depend only on
         (keypoints3d, coarse bank) -- OnePosePlusModel.py:144-156 recomputes them per image -- so
         they are cached per object: the key is the identity AND version counter of both tensors
-        (an in-place edit or a different object re-encodes).  Set `cache_object_tokens = False`
-        to encode per image like the reference."""
+        (an in-place edit or a different object re-encodes; writes that bypass the version counter
+        need `invalidate_object_cache()`).  The tokens carry the event of the stream that produced
+        them, so reuse from another stream is ordered behind the encoding.  Set
+        `cache_object_tokens = False` to encode per image like the reference."""
         if not getattr(self, "cache_object_tokens", True):
             return None
         src = (kpts, bank_c)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src)
         hit = self._rt.get("obj")
         if hit is not None and hit[0] == key and hit[1].device == device:
+            if hit[3] is not None:      # encoded on another stream: order this stream behind that work
+                torch.cuda.current_stream(device).wait_event(hit[3])
             return hit[1]
         n = int(kpts.shape[1])
         tok = torch.empty((n, self.config["loftr_coarse"]["d_model"]), dtype=torch.float32, device=device)
         ws = torch.empty(4096, dtype=torch.uint8, device=device)
         _lib.check(lib.opp_encode_points(ctx, kpts.data_ptr(), bank_c.data_ptr(), n, tok.data_ptr(), ws.data_ptr(),
                                          ws.numel(), stream), "opp_encode_points")
-        self._rt["obj"] = (key, tok, src)     # keep the source tensors alive so the key cannot alias
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._rt["obj"] = (key, tok, src, ev)     # keep the source tensors alive so the key cannot alias
         return tok
+
+    def invalidate_object_cache(self):
+        """Drops the cached 3D-point tokens.  Needed only after writes the key cannot see: the cache is keyed on
+        (data_ptr, tensor._version, shape) of `keypoints3d` and the coarse bank, so edits through `tensor.data`,
+        a raw pointer (custom kernels, IPC-shared banks) or anything else that does not bump `_version` must be
+        followed by this call (or set `cache_object_tokens = False`)."""
+        self._rt["obj"] = None
 
     def _workspace(self, nbytes, device):
         ws = self._rt["ws"]

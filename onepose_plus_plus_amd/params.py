@@ -87,6 +87,9 @@ def transformer_spec(name, tcfg):
             (p + ".norm2.weight", (d,), "ln_weight"),
             (p + ".norm2.bias", (d,), "ln_bias"),
         ]
+    if tcfg.get("final_proj"):      # constructed upstream but never applied (transformer.py:123-124):
+        s += [(name + ".final_proj.weight", (d, d), "xavier"),      # kept so that a strict load of such a checkpoint works
+              (name + ".final_proj.bias", (d,), "linear_b")]
     return s
 
 

@@ -3,8 +3,18 @@
 
 Same call signature and return tuple `(pose [3,4], pose_homo [4,4], inliers, state)`; the
 matches may be CUDA tensors (they then never leave the device until the 12-number pose is read)
-or numpy arrays.  Accuracy-level parity with OpenCV's RANSAC (different sampling), deterministic
-for a given `seed`.  No CPU fallback.
+or numpy arrays.  Deterministic for a given `seed`.  No CPU fallback.
+
+Differences from the reference's `cv2.solvePnPRansac(..., flags=SOLVEPNP_EPNP, iterationsCount=10000)`
+(parity is accuracy-level only -- cv2 is not installed here, so there are no OpenCV fixtures: "parity unpinned"):
+  * minimal solver: Grunert P3P on 3 matches + a 4th for disambiguation, Gauss-Newton refinement on the inliers,
+    instead of EPnP on 4+ matches; same hypothesis budget by default (10000), but every hypothesis is evaluated
+    (OpenCV stops early at confidence 0.99) and the sampling sequence is a hash of (seed, hypothesis), not cv::RNG;
+  * failure convention: fewer than 4 matches, or a degenerate configuration, returns the reference's own
+    `cv2.error` branch -- identity pose, empty inliers, state False (metric_utils.py:197-204); when no hypothesis
+    gathers 4 inliers the best hypothesis is returned with state True and whatever inliers it has, like OpenCV,
+    which reports success with an empty inlier set there;
+  * the pycolmap branch (`use_pycolmap_ransac=True`) is not reproduced: the argument is accepted and ignored.
 """
 import ctypes
 
@@ -23,7 +33,7 @@ def _dev_f32(a, device):
 
 
 def ransac_PnP(K, pts_2d, pts_3d, scale=1, pnp_reprojection_error=5, img_hw=None, use_pycolmap_ransac=False,
-               iterations=4096, refine_iters=8, seed=0, device=None):
+               iterations=10000, refine_iters=8, seed=0, device=None):
     """K [3,3]; pts_2d [M,2] pixels; pts_3d [M,3].  `img_hw` / `use_pycolmap_ransac` are accepted for
     signature compatibility (the pycolmap branch of the reference is not reproduced)."""
     lib = _lib.load()

@@ -32,8 +32,16 @@ class MatcherPool:
     def map(self, items, post=None):
         """Runs `model(data)` for every `data` dict of `items` (tensors already on the device) and
         returns the mutated dicts in input order.  `post(data)` (optional) runs on the worker thread
-        right after the forward, on the forward's stream (e.g. pose.ransac_PnP)."""
+        right after the forward, on the forward's stream (e.g. pose.ransac_PnP).
+
+        Stream contract: the inputs must have been produced on (or be complete with respect to) the stream that
+        is current when `map` is called -- e.g. `ingest.read_grayscale_u8` uploads and resizes asynchronously on
+        it.  Every worker stream first waits for that stream, so a forward never reads a half-written image or
+        bank; on return all worker streams are synchronised."""
         items = list(items)
+        producer = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(producer)
         out = [None] * len(items)
         todo = queue.SimpleQueue()
         for i, d in enumerate(items):
@@ -43,6 +51,7 @@ class MatcherPool:
         def worker(slot):
             torch.cuda.set_device(self.device)
             try:
+                self.streams[slot].wait_event(ready)      # inputs enqueued on the caller's stream are complete first
                 with torch.cuda.stream(self.streams[slot]), torch.no_grad():
                     while True:
                         try:

@@ -74,19 +74,18 @@ def optimise_highconf_bank(name, steps=160, lr=0.05):
     functional forward), image / weights / keypoints fixed.  The result is rounded to fp16-representable values
     and becomes a stored fixture INPUT; the reference is then run on it like on any other input."""
     from oracle import onepose_oracle as O
+    from tests.helpers import highconf_geometry
     hw, n, n_planted, thr, wseed, iseed = HIGHCONF_CASES[name]
     cfg = default_config(thr=thr)
     sd = make_state_dict(cfg, wseed)
     data = make_inputs(n, hw, iseed)
+    _, _, kpts, cells = highconf_geometry(name)      # planted point i projects onto its cell under a known pose
+    data["keypoints3d"] = kpts
     with torch.no_grad():
         feat_c, _ = O.backbone_forward(sd, data["query_image"])
         pe = O.sine_position_table(256, (256, 256))[:, :, :feat_c.size(2), :feat_c.size(3)]
         tokens2d = (feat_c + pe).flatten(2).transpose(1, 2)
         nk = O.normalize_3d_keypoints(data["keypoints3d"])
-    hc, wc = feat_c.shape[2:]
-    g = torch.Generator().manual_seed(1234)
-    interior = torch.tensor([y * wc + x for y in range(2, hc) for x in range(2, wc)])
-    cells = interior[torch.randperm(len(interior), generator=g)[:n_planted]]
     rows = torch.arange(n_planted)
     bank = data["descriptors3d_coarse_db"].clone().requires_grad_(True)
     opt = torch.optim.Adam([bank], lr=lr)
@@ -111,6 +110,7 @@ def gen_highconf():
     cls = load_reference_model_class()
     for name, (hw, n, n_planted, thr, wseed, iseed) in HIGHCONF_CASES.items():
         path = os.path.join(HERE, name + ".npz")
+        from tests.helpers import highconf_geometry
         if os.path.exists(path) and "--reoptimise" not in sys.argv:
             bank16 = torch.from_numpy(np.load(path)["bank_c_f16"])       # keep the committed fixture input
         else:
@@ -119,11 +119,13 @@ def gen_highconf():
         model = cls(cfg).eval()
         model.load_state_dict(make_state_dict(cfg, wseed), strict=True)
         data = make_inputs(n, hw, iseed)
+        data["keypoints3d"] = highconf_geometry(name)[2]
         data["descriptors3d_coarse_db"] = bank16.float()
         with torch.no_grad():
             model(data)
         out = e2e_outputs(data)
         out["bank_c_f16"] = bank16.numpy()
+        out["keypoints3d"] = data["keypoints3d"].numpy()
         np.savez_compressed(path, **out)
         c = data["mconf"]
         print(name, "M =", len(c), " conf > 0.5:", int((c > 0.5).sum()), " max %.4f" % c.max().item())

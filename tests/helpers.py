@@ -13,7 +13,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # Tolerances (north_star): indices bit-exact, confidences / offsets within 1e-4 fp32.
 TOL_CONF = 1e-4
-TOL_OFFSET = 1e-4          # expec_f (normalised window units)
+TOL_OFFSET = 1e-4          # expec_f[:, :2]: the fine offsets (normalised window units)
+# expec_f[:, 2] is NOT an offset: it is sum_xy sqrt(clamp(var, 1e-10)) (fine_matching.py:92-94), whose derivative
+# 1 / (2 sqrt(var)) blows up on sharply peaked heatmaps.  Measured on the high-confidence case (1487 matches): the
+# reference's own fp32 result differs from an fp64 evaluation of the same formula by up to 1.9e-4 in that column
+# (1.2e-5 in the offsets), so the column gets 5x the offset tolerance.
+STD_TOL_FACTOR = 5.0
 TOL_PIXEL = 1e-3           # mkpts_query_f in pixels: offsets * 2 * scale(<=2) -> 4e-4 + fp32 ulp at 512
 
 
@@ -29,13 +34,51 @@ def e2e_setup(name):
     return cfg, sd, data
 
 
+def highconf_geometry(name):
+    """The synthetic object of a high-confidence case: a pinhole camera K, a ground-truth object pose [R | t] and
+    3D keypoints such that planted point i projects exactly onto the coarse-grid coordinate (8 jx, 8 jy) of its
+    planted cell -- so the matches of that case are geometrically consistent and PnP on them must recover the pose.
+    -> K [3,3], pose [3,4] (float64 numpy), keypoints3d [1,n,3] float32 tensor, cells [n_planted] int64 tensor."""
+    hw, n, n_planted, thr, wseed, iseed = HIGHCONF_CASES[name]
+    hc, wc = hw[0] // 8, hw[1] // 8
+    g = torch.Generator().manual_seed(1234)
+    interior = torch.tensor([y * wc + x for y in range(2, hc) for x in range(2, wc)])
+    cells = interior[torch.randperm(len(interior), generator=g)[:n_planted]]
+    K = np.array([[600.0, 0.0, hw[1] / 2.0], [0.0, 600.0, hw[0] / 2.0], [0.0, 0.0, 1.0]])
+    ax = np.array([0.3, -0.5, 0.2])
+    ax = ax / np.linalg.norm(ax)
+    th = np.deg2rad(25.0)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+    t = np.array([0.02, -0.03, 0.6])
+    z = (torch.rand(n, generator=g, dtype=torch.float64) * 0.2 + 0.5).numpy()
+    uv = np.zeros((n, 2))
+    uv[:n_planted, 0] = (cells % wc).numpy() * 8.0
+    uv[:n_planted, 1] = (cells // wc).numpy() * 8.0
+    uv[n_planted:] = (torch.rand(n - n_planted, 2, generator=g, dtype=torch.float64) * torch.tensor([hw[1] - 1.0, hw[0] - 1.0])).numpy()
+    xc = np.stack([(uv[:, 0] - K[0, 2]) / K[0, 0] * z, (uv[:, 1] - K[1, 2]) / K[1, 1] * z, z], 1)
+    xo = (xc - t) @ R          # R^T (x_cam - t), row-vector form
+    return K, np.concatenate([R, t[:, None]], 1), torch.from_numpy(xo.astype(np.float32))[None], cells
+
+
+def pose_errors(pose_pred, pose_gt):
+    """query_pose_error of the reference (src/utils/metric_utils.py:88-104): rotation error in degrees, translation
+    error in cm (poses [3,4] / [4,4], translation in metres)."""
+    Rp, tp, Rg, tg = pose_pred[:3, :3], pose_pred[:3, 3], pose_gt[:3, :3], pose_gt[:3, 3]
+    cos = np.clip((np.trace(Rp.T @ Rg) - 1.0) / 2.0, -1.0, 1.0)
+    return float(np.rad2deg(np.abs(np.arccos(cos)))), float(np.linalg.norm(tp - tg) * 100.0)
+
+
 def highconf_setup(name):
-    """-> cfg, sd, data with the optimised coarse bank of the fixture (stored fp16 values) in place."""
+    """-> cfg, sd, data with the fixture's object (keypoints of `highconf_geometry`, optimised coarse bank stored as
+    fp16 values) in place."""
     hw, n, n_planted, thr, wseed, iseed = HIGHCONF_CASES[name]
     cfg = default_config(thr=thr)
     sd = make_state_dict(cfg, wseed)
     data = make_inputs(n, hw, iseed)
-    data["descriptors3d_coarse_db"] = torch.from_numpy(load_golden(name)["bank_c_f16"]).float()
+    gold = load_golden(name)
+    data["keypoints3d"] = torch.from_numpy(gold["keypoints3d"])
+    data["descriptors3d_coarse_db"] = torch.from_numpy(gold["bank_c_f16"]).float()
     return cfg, sd, data
 
 
@@ -131,7 +174,12 @@ def assert_match_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_p
             g = to_np(got[k])
             assert g.shape == gold[k].shape, (where, k, g.shape, gold[k].shape)
             assert g.dtype == np.float32, (where, k, g.dtype)
-            if g.size:
+            if g.size and k == "expec_f":
+                err = np.abs(g[:, :2] - gold[k][:, :2]).max()
+                assert err <= tol, (where, "expec_f offsets", float(err), tol)
+                err = np.abs(g[:, 2] - gold[k][:, 2]).max()
+                assert err <= STD_TOL_FACTOR * tol, (where, "expec_f std", float(err), STD_TOL_FACTOR * tol)
+            elif g.size:
                 err = np.abs(g - gold[k]).max()
                 assert err <= tol, (where, k, float(err), tol)
     if "conf_matrix" in got and any(k.startswith("conf_") for k in gold):

@@ -51,9 +51,97 @@ def test_e2e_high_confidence_vs_golden(name, precision):
     H.assert_match_outputs(out, gold, where=name)
     rel = H.conf_relative_error(out["mconf"], gold["mconf"])
     absd = float(np.abs(H.to_np(out["mconf"]) - gold["mconf"]).max())
-    print("%s [%s]: M %d, mconf max abs err %.2e, max rel err %.2e, expec_f max abs err %.2e" %
-          (name, precision, len(gold["mconf"]), absd, rel, float(np.abs(H.to_np(out["expec_f"]) - gold["expec_f"]).max())))
+    de = np.abs(H.to_np(out["expec_f"]) - gold["expec_f"])
+    print("%s [%s]: M %d, mconf max abs err %.2e, max rel err %.2e, fine offsets max abs err %.2e, std column %.2e" %
+          (name, precision, len(gold["mconf"]), absd, rel, float(de[:, :2].max()), float(de[:, 2].max())))
     assert rel < 1e-3
+
+
+def test_worker_flow_recovers_pose():
+    """The data flow of the reference's worker (`extract_matches`, inference_OnePosePlus_worker.py:7-37: model(data)
+    then compute_query_pose_errors -> ransac_PnP on `mkpts_query_f` / `mkpts_3d_db`, metric_utils.py:221-270) through
+    the drop-in aliases (`dropin.install`), on the synthetic object of the high-confidence case whose planted
+    points project onto their cells under a known pose: the pose comes back from the ~1490 HIP matches."""
+    import sys
+    from onepose_plus_plus_amd import dropin
+    from onepose_plus_plus_amd.pose import ransac_PnP
+    name = "highconf_512x512_n3000"
+    cfg, sd, data = H.highconf_setup(name)
+    K, pose_gt, kpts, cells = H.highconf_geometry(name)
+    assert torch.equal(kpts, data["keypoints3d"])
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "src" or k.startswith("src.")}
+    try:
+        dropin.install(pnp=False)
+        from src.models.OnePosePlus.OnePosePlusModel import OnePosePlus_model as RefPathModel   # inference_OnePosePlus.py:11
+        match_model = RefPathModel(cfg)                              # build_model: constructor, strict load, eval
+        match_model.load_state_dict({k: v for k, v in sd.items()}, strict=True)
+        match_model.eval()
+        match_model.cuda()                                           # worker: inference_OnePosePlus_worker.py:43
+        data_c = {k: v.cuda() if isinstance(v, torch.Tensor) else v for k, v in data.items()}
+        data_c["query_intrinsic"] = torch.from_numpy(K)[None].cuda()
+        data_c["query_pose_gt"] = torch.from_numpy(np.concatenate([pose_gt, [[0, 0, 0, 1.0]]]))[None].cuda()
+        with torch.no_grad():
+            match_model(data_c)
+    finally:
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            if k not in saved:
+                del sys.modules[k]
+    # compute_query_pose_errors (metric_utils.py:221-270) with the on-device solver and the reference's settings
+    m_bids = data_c["m_bids"]
+    assert (m_bids == 0).all() and len(m_bids) > 1400
+    pose, homo, inliers, state = ransac_PnP(data_c["query_intrinsic"][0].cpu().numpy(), data_c["mkpts_query_f"],
+                                            data_c["mkpts_3d_db"], scale=1000, pnp_reprojection_error=5,
+                                            img_hw=[512, 512], use_pycolmap_ransac=False)
+    assert state and pose.shape == (3, 4) and homo.shape == (4, 4)
+    r_err, t_err = H.pose_errors(pose, data_c["query_pose_gt"][0].cpu().numpy())
+    print("worker flow: %d matches, %d inliers, R err %.3f deg, t err %.3f cm" % (len(m_bids), len(inliers), r_err, t_err))
+    assert len(inliers) > 0.8 * len(m_bids)
+    assert r_err < 1.0 and t_err < 1.0                                # the 1 cm / 1 deg bar of the reference's metrics
+
+
+def _scaled_backbone(sd, S):
+    """The same network with every activation of the ResNet stages multiplied by the power of two S: stem BN affine
+    x S, running means / shifts of the stage BNs x S, the three FPN laterals x 1/S.  All of it commutes exactly with
+    fp32 arithmetic (and with the bf16x3 split), so the reference's outputs are bit-identical to the unscaled ones."""
+    import re
+    big = {k: v.clone() for k, v in sd.items()}
+    big["backbone.bn1.weight"] = sd["backbone.bn1.weight"] * S
+    big["backbone.bn1.bias"] = sd["backbone.bn1.bias"] * S
+    for k in sd:
+        if re.match(r"backbone\.layer[123]\.\d\.(bn\d|downsample\.1)\.(bias|running_mean)$", k):
+            big[k] = sd[k] * S
+    for k in ("backbone.layer3_outconv.weight", "backbone.layer2_outconv.weight", "backbone.layer1_outconv.weight"):
+        big[k] = sd[k] / S
+    return big
+
+
+@pytest.mark.parametrize("scale_log2", [18, -20])
+def test_activation_range_1e5_and_1e_minus_6(scale_log2):
+    """Backbone activations of ~1.5e5..1.2e6 (S = 2^18, beyond the fp16 range) and of ~1e-6 (S = 2^-20): the default
+    bf16x3 arithmetic and fp32 reproduce the reference's golden outputs unchanged (the scaled network is exactly
+    equivalent).  The opt-in fp16x2 fast mode detects the overflow on the device, re-runs in bf16x3 and stays there;
+    at 1e-6 (no overflow, but fp16's absolute 2^-25 floor) it is simply not required to meet the bar."""
+    from tests import hip_ops as ops
+    name = "e2e_128x128_n300_thr0"
+    cfg, sd, data = H.e2e_setup(name)
+    big = _scaled_backbone(sd, 2.0 ** scale_log2)
+    gold = H.load_golden(name)
+    outs = {}
+    for precision in ("bf16x3", "fp32"):
+        outs[precision] = ops.run_model(ops.make_model(cfg, big, precision), data)
+        H.assert_match_outputs(outs[precision], gold, where="%s at 2^%d" % (precision, scale_log2))
+    plain = ops.run_model(ops.make_model(cfg, sd, "bf16x3"), data)
+    assert torch.equal(plain["conf_matrix"], outs["bf16x3"]["conf_matrix"])        # the split commutes with 2^k
+    if scale_log2 > 0:
+        m = ops.make_model(cfg, sd, "fp16x2_all")
+        ops.run_model(m, data)
+        assert m.gemm_precision == "fp16x2_all"                         # in range: the guard stays quiet
+        m = ops.make_model(cfg, big, "fp16x2_all")
+        with pytest.warns(UserWarning, match="fp16 range"):
+            out = ops.run_model(m, data)
+        assert m.gemm_precision == "bf16x3"                             # sticky switch to the safe arithmetic
+        assert torch.equal(out["conf_matrix"], outs["bf16x3"]["conf_matrix"])
+        H.assert_match_outputs(out, gold, where="guard fallback")
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

@@ -61,5 +61,5 @@ def test_pnp_device_inputs_determinism_and_failure():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])   # device / host inputs, same seed
     pose, homo, inl, ok = ransac_PnP(K, uv[:3], X[:3])                  # < 4 matches: reference's failure convention
     assert not ok and np.array_equal(pose, np.eye(4)[:3]) and inl.size == 0
-    pose, homo, inl, ok = ransac_PnP(K, rng.uniform(0, 512, (50, 2)), X[:50])   # pure outliers: no consensus or a tiny one
-    assert (not ok) or len(inl) < 15
+    pose, homo, inl, ok = ransac_PnP(K, rng.uniform(0, 512, (50, 2)), X[:50])   # pure outliers: a tiny consensus at most,
+    assert ok and len(inl) < 15                                                   # reported as success like OpenCV does

@@ -2,9 +2,10 @@
 tools/pmc_bench.sh.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B:
 MI355X_MICROARCH.md §HBM); both counters are in KiB.
 
-    python tools/pmc_traffic_summary.py gpurun_out/pmc_bench profiles/r01_pmc_hbm_traffic.csv [profiles/traffic_gemm_symbols.json]
+    python tools/pmc_traffic_summary.py gpurun_out/pmc_bench profiles/r02_pmc_hbm_traffic.csv profiles/traffic_symbols_bf16x3.json
 """
 import collections
+import re
 import csv
 import json
 import os
@@ -33,14 +34,20 @@ def main(d, out):
         wr.writerow(["Kernel", "Launches", "FetchBytesPerLaunch(x2 corrected)", "WriteBytesPerLaunch"])
         for r in rows:
             wr.writerow([r[0], r[1], "%.0f" % r[2], "%.0f" % r[3]])
-    # per GEMM symbol (template argument string) -> bytes per launch, read by bench.py's roofline leg
+    # per kernel symbol -> bytes per launch, read by bench.py's roofline leg: GEMM kernels are keyed by their template
+    # argument string, every other kernel by its bare function name
     sym = {}
     for k, n, fb, wb in rows:
         if "opp_gemm_kernel<" in k:
             t = k[k.find("<") + 1:k.find(">")]
-            sym[t] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
-                      "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
-                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py; FETCH x2 gfx950 correction"}
+        else:
+            m = re.search(r"(?:::|^|\s)([A-Za-z_]\w*)\s*(?:<[^()]*>)?\(", k.replace("(anonymous namespace)", ""))
+            t = m.group(1) if m else k
+        if t in sym:      # several instantiations of one non-GEMM kernel: keep the one with the most traffic (first)
+            continue
+        sym[t] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+                  "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
+                  "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py; FETCH x2 gfx950 correction"}
     jpath = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(out), "traffic_gemm_symbols.json")
     with open(jpath, "w") as f:
         json.dump(sym, f, indent=1)
