@@ -75,6 +75,17 @@ int opp_version(void);
  * returns the state-dict key expected at index i. */
 int opp_create(const opp_config* cfg, opp_ctx** out);
 void opp_destroy(opp_ctx* ctx);
+/* query_image_mask of the CURRENT sample (OnePosePlusModel.py:158: data['query_image_mask'].flatten(-2)): device
+ * array of L = hc*wc floats, 1 = valid image cell, 0 = padding; NULL (default) = no mask.  Applies to the coarse
+ * transformer (phi(Q), phi(K), V rows of masked image tokens are zeroed, linear_attention.py:49-53) and to the coarse
+ * matcher (-1e9 added to the masked columns of the score matrix, coarse_matching.py:108-114) in every later call made
+ * through this ctx: opp_transformer (which = 0, n_seg = 1), opp_coarse_match, opp_forward_coarse. */
+int opp_set_query_mask(opp_ctx* ctx, const float* mask);
+/* B > 1 (quirk of normalize_3d_keypoints, utils/normalize.py:20-21): the 3D keypoints of EVERY batch element are scaled
+ * by the bounding-box extent of batch element 0 and centred on their own mean.  kpts0 [n0][3] = the keypoints of
+ * batch element 0 (NULL = each cloud uses its own extent, the B = 1 behaviour).  Applies to opp_encode_points,
+ * opp_coarse_tokens and opp_forward_coarse. */
+int opp_set_keypoint_extent_ref(opp_ctx* ctx, const float* kpts0, int n0);
 /* fp16x2 range guard (gemm_precision 1 / 2 only; a no-op otherwise): `flag` is a device int that every stage
  * enqueued through this ctx ORs with 1 when an fp16x2 GEMM produced a non-finite value, i.e. an activation left the
  * fp16 range (|x| >~ 1.3e5) -- or the input itself was not finite.  The caller zeroes it, reads it after the

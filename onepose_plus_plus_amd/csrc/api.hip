@@ -87,6 +87,9 @@ struct opp_ctx {
   bool packed = false;
   size_t packed_bytes = 0;
   int* status_flag = nullptr;      // opp_set_status_flag
+  const float* query_mask = nullptr;      // opp_set_query_mask: [L] floats (0 / 1) of the CURRENT sample, or null
+  const float* kpt_extent_ref = nullptr;  // opp_set_keypoint_extent_ref: keypoints of batch element 0 (quirk q4)
+  int kpt_extent_n = 0;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
 };
@@ -223,6 +226,17 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
 }
 
 extern "C" void opp_destroy(opp_ctx* ctx) { delete ctx; }
+extern "C" int opp_set_query_mask(opp_ctx* ctx, const float* mask) {
+  OPP_CHECK_ARG(ctx, "set_query_mask: null ctx");
+  ctx->query_mask = mask;
+  return OPP_OK;
+}
+extern "C" int opp_set_keypoint_extent_ref(opp_ctx* ctx, const float* kpts0, int n0) {
+  OPP_CHECK_ARG(ctx && (kpts0 == nullptr || n0 > 0), "set_keypoint_extent_ref: bad argument");
+  ctx->kpt_extent_ref = kpts0;
+  ctx->kpt_extent_n = kpts0 ? n0 : 0;
+  return OPP_OK;
+}
 extern "C" int opp_set_status_flag(opp_ctx* ctx, int* flag) {
   OPP_CHECK_ARG(ctx, "set_status_flag: null ctx");
   ctx->status_flag = flag;
@@ -557,11 +571,20 @@ int encode_points_impl(opp_ctx* c, const float* kpts, const float* bank_c, int n
   const int C = c->cfg.coarse_d_model;
   if (c->cfg.kpt_enc_enable) {
     float* stats = a.f(8);
+    float* stats0 = a.f(8);
     if (!a.ok) {
       opp_set_error("encode_points: workspace too small");
       return OPP_ERR_WORKSPACE;
     }
     OPP_TRY(opp_kpt_stats(kpts, n, stats, s));               // utils/normalize.py:16-26
+    if (c->kpt_extent_ref && c->kpt_extent_ref != kpts) {
+      // B > 1: the scaling comes from the bbox extent of batch element 0, the centre from this sample (quirk q4)
+      OPP_TRY(opp_kpt_stats(c->kpt_extent_ref, c->kpt_extent_n, stats0, s));
+      if (hipMemcpyAsync(stats + 3, stats0 + 3, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        opp_set_error("encode_points: copy failed");
+        return OPP_ERR_LAUNCH;
+      }
+    }
     return opp_kpt_encode(kpts, stats, bank_c, n, c->kpt_wt, c->kpt_b, t3, C, s);
   }
   return opp_bank_transpose(bank_c, n, C, t3, C, s);
@@ -649,7 +672,7 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
 
 // LocalFeatureTransformer.forward (transformer.py:133-171) on X = [stream0 ; stream1]
 int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cross, int C, int nhead, float* X, int n_seg,
-                     int len0, int len1, Arena& a, hipStream_t s, int h2) {
+                     int len0, int len1, Arena& a, hipStream_t s, int h2, const float* mask0 = nullptr) {
   const int D = C / nhead;
   const int T0 = n_seg * len0, T1 = n_seg * len1, T = T0 + T1;
   if (T == 0 || layers.empty()) return OPP_OK;
@@ -690,6 +713,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.split_row = T0;
       g.s0 = (float)len0;
       g.s1 = (float)len1;
+      g.row_mask = mask0;        // query_image_mask over the image tokens (stream 0), or null
+      g.row_mask_rows = T0;
       g.prec = h2;
       g.h2_inv = (h2 == OPP_PREC_FP16X2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
@@ -764,7 +789,8 @@ extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg
   OPP_CHECK_ARG(which == 0 || which == 1, "transformer: which must be 0 or 1");
   Arena a(ws, ws_bytes);
   if (which == 0)
-    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg));
+    return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg),
+                            n_seg == 1 ? ctx->query_mask : nullptr);
   return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg));
 }
 
@@ -802,6 +828,7 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   g.n_store = L;
   g.out_mul = 1.0f / (float)C;
   g.out_div = (float)((double)c->cfg.match_temperature + 1e-4);
+  g.col_mask = c->query_mask;      // masked image cells get -1e9 (coarse_matching.py:108-114), or null
   // tile rows of the score GEMM: 128 (config 0 / 25); bf16x3 with enough rows: the 256x128 8-wave tile (config 20)
   const int score_cfg = sprec == OPP_PREC_BF16X3 ? (n >= 512 ? 20 : 25) : 0;
   const int score_bm = score_cfg == 20 ? 256 : 128;
@@ -897,7 +924,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   a.off = mark;
   OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;
-  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg)));
+  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg), ctx->query_mask));
   a.off = mark;
   return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
                            mkpts_3d, count, a, s);

@@ -618,6 +618,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           acc[i][j][r] = scale_on ? (cv0 * g.out_mul) / g.out_div : cv0;
         }
   }
+  if (g.col_mask != nullptr) {   // masked image cells: sim += -1e9 (coarse_matching.py:108-114); lane = column
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      const float add = (col < g.n_store && g.col_mask[col] == 0.f) ? -1e9f : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += add;
+    }
+  }
   if constexpr (H2) {
     if (g.nonfinite != nullptr) {   // range guard: |x| beyond the fp16 range shows up as inf / NaN accumulators
       bool bad = false;
@@ -899,6 +910,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           const float vdiv = row < g.split_row ? g.s0 : g.s1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] / vdiv;
+        }
+        if (g.row_mask != nullptr && row < g.row_mask_rows) {   // padded image tokens: Q, K, V rows -> 0 (linear_attention.py:49-53)
+          const float rm = g.row_mask[row];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= rm;
         }
       }
       float* cp = g.C + (size_t)row * g.ldc + col;

@@ -82,6 +82,13 @@ struct OppGemm {
   int qk_cols = 0;     // OPP_ACT_QKV: columns < qk_cols get elu(x)+1, the rest x / seg_len(row)
   int split_row = 0;   // rows < split_row divide by s0, others by s1
   float s0 = 1.f, s1 = 1.f;
+  // query_image_mask support (linear_attention.py:49-53, coarse_matching.py:108-114):
+  //   row_mask  OPP_ACT_QKV only: rows < row_mask_rows (the image tokens) get phi(Q), phi(K) and V / S multiplied by
+  //             row_mask[row] (0 / 1 floats)
+  //   col_mask  score GEMM: -1e9 is added to every column whose col_mask[col] == 0, after the temperature scaling
+  const float* row_mask = nullptr;
+  int row_mask_rows = 0;
+  const float* col_mask = nullptr;
   // generic output scaling: y = acc * out_mul / out_div (applied first; used by the score GEMM)
   float out_mul = 1.f, out_div = 1.f;
   // operand extents in bytes for the buffer descriptors (filled by the launcher)

@@ -373,32 +373,95 @@ class OnePosePlus_model(nn.Module):
             t = t.float()
         return t.contiguous()
 
-    def _range_fallback(self, data):
+    def _range_fallback(self, data, use_token_cache=True, sample=None):
         """fp16x2 range guard tripped (include/opp_hip.h `opp_set_status_flag`): this forward and all later ones
         run in bf16x3, which has the full fp32 exponent range."""
         warnings.warn("onepose_plus_plus_amd: activations left the fp16 range of gemm_precision %r (or the input is not "
                       "finite); re-running in 'bf16x3' and keeping that arithmetic" % (self.gemm_precision,))
-        self.set_gemm_precision("bf16x3")
-        return self.forward(data)
+        self.set_gemm_precision("bf16x3")          # new C context: _forward_single re-applies the per-sample state
+        return self._forward_single(data, use_token_cache, sample)
 
     def forward(self, data):
-        """Same contract as the reference forward (OnePosePlusModel.py:96-201); updates `data`."""
+        """Same contract as the reference forward (OnePosePlusModel.py:96-201); updates `data`.
+        B = 1 without `query_image_mask` (what inference.py runs) takes the fused single-call path; B > 1 and / or a
+        `query_image_mask` [B, H/8, W/8] run sample by sample through the same kernels (`_forward_batch`)."""
         if self.training:
             raise RuntimeError("onepose_plus_plus_amd.OnePosePlus_model is inference-only: call .eval() "
                                "(training through the HIP path is not implemented; SURVEY.md §8f-3)")
-        if "query_image_mask" in data:
-            raise NotImplementedError("query_image_mask is not supported by the HIP path (unexercised upstream: "
-                                      "every shipped config has img_pad False)")
         img = data["query_image"]
         if not torch.is_tensor(img) or not img.is_cuda:
             raise RuntimeError("query_image must be a CUDA/ROCm tensor: the HIP path has no CPU fallback")
+        if img.dim() != 4 or img.size(1) != 1 or img.size(0) < 1:
+            raise NotImplementedError("HIP path supports query_image of shape [B,1,H,W] (got %s)" % (tuple(img.shape),))
+        if img.size(0) > 1 or "query_image_mask" in data:
+            return self._forward_batch(data)
+        return self._forward_single(data)
+
+    def _forward_batch(self, data):
+        """B >= 1 with optional `query_image_mask`: every sample runs the B = 1 path with its own mask
+        (linear_attention.py:49-53, coarse_matching.py:108-114) and with the keypoint scaling of batch element 0
+        (normalize.py:20-21, quirk q4); the per-sample results are concatenated in batch order, which is the order
+        `torch.where` gives the reference (coarse_matching.py:170)."""
+        img = data["query_image"]
         device = img.device
-        if img.dim() != 4 or img.size(0) != 1 or img.size(1) != 1:
-            raise NotImplementedError("HIP path supports query_image of shape [1,1,H,W] (got %s)" % (tuple(img.shape),))
+        B = int(img.size(0))
+        H, W = int(img.shape[2]), int(img.shape[3])
+        if H % 8 or W % 8:
+            raise RuntimeError("image size must be a multiple of 8, got %dx%d" % (H, W))
+        hc, wc = H // 8, W // 8
+        mask = None
+        if "query_image_mask" in data:
+            m = data["query_image_mask"]
+            if not torch.is_tensor(m) or m.device != device:
+                raise RuntimeError("query_image_mask must be a tensor on %s" % (device,))
+            if tuple(m.shape) != (B, hc, wc):
+                # the reference flattens the mask and broadcasts it against the hc*wc image tokens
+                # (OnePosePlusModel.py:158, linear_attention.py:49-53): any other shape fails there as well
+                raise RuntimeError("query_image_mask must have the coarse resolution [B=%d, %d, %d], got %s"
+                                   % (B, hc, wc, tuple(m.shape)))
+            mask = m.flatten(-2).to(torch.float32).contiguous()
+        per_sample = ("keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db", "query_image", "query_image_scale")
+        for k in per_sample:
+            if k in data and (not torch.is_tensor(data[k]) or data[k].size(0) != B):
+                raise RuntimeError("%s must have batch size %d" % (k, B))
+        kpts0 = self._f32(data["keypoints3d"][0:1], "keypoints3d", device)
+        outs = []
+        for b in range(B):
+            d = {k: data[k][b:b + 1] for k in per_sample if k in data}
+            sample = (mask[b] if mask is not None else None, kpts0 if b > 0 else None)
+            self._forward_single(d, use_token_cache=False, sample=sample)
+            outs.append(d)
+        first = outs[0]
+        data.update({"bs": B, "q_hw_i": img.shape[2:], "q_hw_c": first["q_hw_c"], "q_hw_f": first["q_hw_f"]})
+        if "W" in first:
+            data["W"] = first["W"]
+        cat = lambda k: torch.cat([o[k] for o in outs], 0)
+        b_ids = torch.cat([torch.full_like(o["b_ids"], b) for b, o in enumerate(outs)], 0)
+        data.update({"conf_matrix": cat("conf_matrix"), "b_ids": b_ids, "i_ids": cat("i_ids"), "j_ids": cat("j_ids"),
+                     "gt_mask": cat("gt_mask"), "m_bids": b_ids, "mkpts_3d_db": cat("mkpts_3d_db"),
+                     "mkpts_query_c": cat("mkpts_query_c"), "mconf": cat("mconf")})
+        if not self.config["fine_matching"]["enable"]:
+            data["mkpts_query_f"] = data["mkpts_query_c"]
+            return
+        if b_ids.numel() == 0:
+            data.update({"expec_f": torch.empty(0, 3, device=device), "mkpts_query_f": data["mkpts_query_c"]})
+            return
+        data.update({"expec_f": torch.cat([o["expec_f"].reshape(-1, 3) for o in outs], 0),
+                     "mkpts_query_f": torch.cat([o["mkpts_query_f"].reshape(-1, 2) for o in outs], 0)})
+
+    def _forward_single(self, data, use_token_cache=True, sample=None):
+        """One sample (B = 1) through the fused coarse call + the fine call.  `sample` = (query mask [L] floats or
+        None, keypoints of batch element 0 or None) of a `_forward_batch` sample."""
+        img = data["query_image"]
+        device = img.device
         cfg = self.config
         with torch.cuda.device(device):
             lib, ctx = self._ensure_ready(device)
             stream = torch.cuda.current_stream(device).cuda_stream
+            smask, sref = sample if sample is not None else (None, None)
+            _lib.check(lib.opp_set_query_mask(ctx, smask.data_ptr() if smask is not None else None), "opp_set_query_mask")
+            _lib.check(lib.opp_set_keypoint_extent_ref(ctx, sref.data_ptr() if sref is not None else None,
+                                                       int(sref.shape[1]) if sref is not None else 0), "opp_set_keypoint_extent_ref")
             H, W = int(img.shape[2]), int(img.shape[3])
             if H % 8 or W % 8:
                 raise RuntimeError("image size must be a multiple of 8, got %dx%d" % (H, W))
@@ -435,7 +498,7 @@ class OnePosePlus_model(nn.Module):
             ws_bytes = lib.opp_forward_coarse_workspace_bytes(ctx, H, W, N)
             ws = self._workspace(ws_bytes, device)
             scale_c = float(H) / float(hc)                                               # coarse_matching.py:222
-            tok3d = self._object_tokens(lib, ctx, kpts, bank_c, device, stream)
+            tok3d = self._object_tokens(lib, ctx, kpts, bank_c, device, stream) if use_token_cache else None
             _lib.check(lib.opp_forward_coarse(
                 ctx, img_c.data_ptr(), H, W, pe.data_ptr() if pe is not None else None, kpts.data_ptr(),
                 bank_c.data_ptr(), tok3d.data_ptr() if tok3d is not None else None, N, scale_c, qscale.data_ptr() if qscale is not None else None,
@@ -445,7 +508,7 @@ class OnePosePlus_model(nn.Module):
             with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
                 M, flag = count.tolist()                                                 # the one D2H sync
             if flag:
-                return self._range_fallback(data)
+                return self._range_fallback(data, use_token_cache, sample)
             b_ids = torch.zeros(M, dtype=torch.int64, device=device)
             data.update({
                 "conf_matrix": conf,
@@ -475,7 +538,7 @@ class OnePosePlus_model(nn.Module):
                 1 if cfg["loftr_fine"]["enable"] else 0, expec.data_ptr(), mk_f.data_ptr(), fws.data_ptr(),
                 fws.numel(), stream), "opp_fine")
             if guarded and int(count[1].item()):       # fine-stage GEMMs (fast mode only: one more sync)
-                return self._range_fallback(data)
+                return self._range_fallback(data, use_token_cache, sample)
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             # keep every tensor whose pointer was handed to the stream alive until here
             self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, feat_f)

@@ -39,3 +39,11 @@ FINE_CASES = {
     "fine_m500": (5000, (512, 512), 500, 5),
     "fine_m1": (100, (64, 96), 1, 6),
 }
+
+# batched + masked forward (B > 1, `query_image_mask` at coarse resolution, per-sample image scales): exercises the
+# keypoint-extent quirk q4, the mask paths of linear attention / coarse matching and the (b, i) match order.
+# name -> (hw, n_points, thr, weight_seed, [input seeds], masked)
+BATCH_CASES = {
+    "e2e_b2_mask_64x96_n200": ((64, 96), 200, 0.0, 0, [3, 4], True),
+    "e2e_b3_128x128_n300": ((128, 128), 300, 0.0, 0, [1, 5, 6], False),
+}

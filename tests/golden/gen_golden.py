@@ -20,7 +20,7 @@ from oracle.refload import load_reference_model_class, load_reference_modules  #
 from onepose_plus_plus_amd.config import default_config  # noqa: E402
 from onepose_plus_plus_amd.synthetic import (make_state_dict, make_inputs,  # noqa: E402
                                              make_planted_matcher_inputs, make_fine_ids)
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES  # noqa: E402
+from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -131,6 +131,34 @@ def gen_highconf():
         print(name, "M =", len(c), " conf > 0.5:", int((c > 0.5).sum()), " max %.4f" % c.max().item())
 
 
+def conf_digest_batched(conf):
+    """[B,N,L] -> per-sample reductions (stacked) + the whole matrix when small"""
+    out = {"conf_rowsum": conf.sum(2).numpy(), "conf_colsum": conf.sum(1).numpy(),
+           "conf_rowmax": conf.max(2).values.numpy(), "conf_colmax": conf.max(1).values.numpy()}
+    if conf.numel() <= 400000:
+        out["conf_matrix"] = conf.numpy()
+    return out
+
+
+def gen_batch():
+    from tests.helpers import batch_setup
+    cls = load_reference_model_class()
+    for name in BATCH_CASES:
+        cfg, sd, data = batch_setup(name)
+        model = cls(cfg).eval()
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            model(data)
+        out = {}
+        for k in ["b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mkpts_3d_db", "mkpts_query_c", "mconf", "expec_f",
+                  "mkpts_query_f"]:
+            out[k] = data[k].numpy()
+        out.update(conf_digest_batched(data["conf_matrix"]))
+        out["meta"] = np.array([data["bs"], *data["q_hw_i"], *data["q_hw_c"], *data["q_hw_f"], data.get("W", -1)], dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "M =", len(data["mconf"]), "per sample:", torch.bincount(data["b_ids"], minlength=int(data["bs"])).tolist())
+
+
 def gen_e2e():
     cls = load_reference_model_class()
     for name, (hw, n, thr, wseed, iseed, fine) in E2E_CASES.items():
@@ -224,7 +252,7 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     steps = {"stages": gen_stage_features, "matcher": gen_matcher, "fine": gen_fine, "e2e": gen_e2e,
-             "transformer": gen_transformer, "highconf": gen_highconf}
+             "transformer": gen_transformer, "highconf": gen_highconf, "batch": gen_batch}
     for k, fn in steps.items():
         if not only or k in only:
             fn()

@@ -7,7 +7,7 @@ import torch
 from onepose_plus_plus_amd.config import default_config
 from onepose_plus_plus_amd.synthetic import (make_state_dict, make_inputs,
                                              make_planted_matcher_inputs, make_fine_ids)
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES
+from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -31,6 +31,25 @@ def e2e_setup(name):
     cfg = default_config(thr=thr, fine=fine)
     sd = make_state_dict(cfg, wseed)
     data = make_inputs(n, hw, iseed)
+    return cfg, sd, data
+
+
+def batch_setup(name):
+    """-> cfg, sd, data of a B > 1 case: per-sample clouds / images, distinct image scales, optional coarse mask"""
+    hw, n, thr, wseed, seeds, masked = BATCH_CASES[name]
+    cfg = default_config(thr=thr)
+    sd = make_state_dict(cfg, wseed)
+    parts = [make_inputs(n, hw, sd_) for sd_ in seeds]
+    data = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    B = len(seeds)
+    data["query_image_scale"] = torch.tensor([[1.0 + 0.25 * b, 1.0 - 0.125 * b] for b in range(B)])
+    data["keypoints3d"] = data["keypoints3d"] * torch.tensor([1.0 + 0.5 * b for b in range(B)]).view(B, 1, 1)   # extents differ
+    if masked:
+        hc, wc = hw[0] // 8, hw[1] // 8
+        m = torch.ones(B, hc, wc)
+        m[0, :, wc - 3:] = 0            # right padding of sample 0
+        m[1, hc - 2:, :] = 0            # bottom padding of sample 1
+        data["query_image_mask"] = m
     return cfg, sd, data
 
 
@@ -139,6 +158,21 @@ def conf_digest_t(conf):
     else:
         out["conf_sample"] = c[::37, ::41].contiguous().numpy()
     return out
+
+
+def assert_batched_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_px=TOL_PIXEL, where=""):
+    """B > 1: same checks as assert_match_outputs with a [B,N,L] confidence matrix"""
+    conf = got["conf_matrix"].float().cpu()
+    dig = {"conf_rowsum": conf.sum(2).numpy(), "conf_colsum": conf.sum(1).numpy(),
+           "conf_rowmax": conf.max(2).values.numpy(), "conf_colmax": conf.max(1).values.numpy(), "conf_matrix": conf.numpy()}
+    for k, v in dig.items():
+        if k in gold:
+            err = np.abs(v - gold[k]).max()
+            assert err <= tol_conf * (50 if k.endswith("sum") else 1), (where, k, float(err))
+    rest = {k: v for k, v in gold.items() if not k.startswith("conf_")}
+    assert_match_outputs({k: v for k, v in got.items() if k != "conf_matrix"}, rest, tol_conf, tol_off, tol_px, where)
+    meta = gold["meta"]
+    assert got["bs"] == meta[0] and tuple(got["q_hw_i"]) == tuple(meta[1:3]) and tuple(got["q_hw_c"]) == tuple(meta[3:5])
 
 
 def assert_transformer_digest(got, gold, rel, where=""):

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES, HIGHCONF_CASES
+from tests.golden.cases import E2E_CASES, HIGHCONF_CASES, BATCH_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -55,6 +55,25 @@ def test_e2e_high_confidence_vs_golden(name, precision):
     print("%s [%s]: M %d, mconf max abs err %.2e, max rel err %.2e, fine offsets max abs err %.2e, std column %.2e" %
           (name, precision, len(gold["mconf"]), absd, rel, float(de[:, :2].max()), float(de[:, 2].max())))
     assert rel < 1e-3
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", list(BATCH_CASES))
+def test_batched_masked_vs_golden(name, precision):
+    """B > 1 with per-sample point clouds / image scales and a coarse-resolution `query_image_mask` against the
+    reference: the mask path of linear attention and of the coarse matcher, the batch-0 keypoint extent (quirk q4)
+    and the (b, i) ordering of the concatenated matches."""
+    from tests import hip_ops as ops
+    cfg, sd, data = H.batch_setup(name)
+    out = ops.run_model(ops.make_model(cfg, sd, precision), data)
+    gold = H.load_golden(name)
+    assert len(gold["mconf"]) > 0 and len(np.unique(gold["b_ids"])) == len(BATCH_CASES[name][4])
+    H.assert_batched_outputs(out, gold, where=name)
+    if "query_image_mask" in data:      # masked cells carry exactly zero confidence and are never matched
+        m = data["query_image_mask"].flatten(-2).bool()
+        conf = out["conf_matrix"].cpu()
+        assert (conf.transpose(1, 2)[~m] == 0).all()
+        assert m[out["b_ids"].cpu(), out["j_ids"].cpu()].all()
 
 
 def test_worker_flow_recovers_pose():

@@ -102,8 +102,9 @@ def test_inference_only_and_no_cpu_fallback():
     m.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"query_image": torch.zeros(1, 1, 64, 64)})
-    with pytest.raises(NotImplementedError):
-        m({"query_image": torch.zeros(1, 1, 64, 64), "query_image_mask": torch.ones(1, 8, 8)})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # masks / batches are supported, CPU tensors are not
+        m({"query_image": torch.zeros(2, 1, 64, 64), "query_image_mask": torch.ones(2, 8, 8)})
+
 
 
 def test_product_never_imports_oracle():

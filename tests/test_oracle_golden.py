@@ -8,7 +8,7 @@ import torch
 from oracle import onepose_oracle as O
 from oracle.refload import reference_available, load_reference_model_class
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES
+from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES
 
 SMALL_E2E = [n for n in E2E_CASES if "512" not in n]
 
@@ -68,6 +68,14 @@ def test_oracle_highconf_vs_golden(name):
     rel = H.conf_relative_error(data["mconf"], gold["mconf"])
     print("%s: oracle vs reference mconf max rel err %.2e" % (name, rel))
     assert rel < 1e-4
+
+
+@pytest.mark.parametrize("name", list(BATCH_CASES))
+def test_oracle_batched_masked_vs_golden(name):
+    """B > 1, per-sample clouds and scales, coarse-resolution `query_image_mask`."""
+    cfg, sd, data = H.batch_setup(name)
+    O.forward(sd, data, cfg)
+    H.assert_batched_outputs(data, H.load_golden(name), tol_conf=2e-5, tol_off=5e-5, tol_px=2e-4, where=name)
 
 
 @pytest.mark.parametrize("name", list(MATCHER_CASES))
