@@ -100,6 +100,26 @@ size_t opp_packed_weights_bytes(const opp_ctx* ctx);
 int opp_pack_weights(opp_ctx* ctx, const float* const* weights, int n_weights, void* packed,
                      size_t packed_bytes, void* stream);
 
+/* ---- training-mode forward of the backbone ------------------------------
+ * PL_OnePosePlus.training_step runs the same module in train() mode (src/lightning_model/
+ * OnePosePlus_lightning_model.py:54-81): every nn.BatchNorm2d of the ResNet-FPN then normalises with the statistics of
+ * the current batch over (B, H, W) and updates its running statistics (backbone/resnet.py:25-26, :101-113; plain
+ * BatchNorm, no SyncBN upstream).  opp_pack_train_weights packs the backbone convolutions WITHOUT the folded
+ * BatchNorm (after opp_pack_weights, same `weights` table; the BatchNorm affine tensors of that table are read in
+ * place during the forward and must stay alive).  opp_backbone_train: image [B][H][W]; feat_c [B][H/8][W/8][256],
+ * feat_f [B][H/2][W/2][128] (NHWC); bn_stats (may be NULL) receives, for BatchNorm layer i of opp_bn_layer_name(i),
+ * 512 floats: [0, C) the batch mean, [C, 2C) the UNBIASED batch variance -- what the caller folds into
+ * running_mean / running_var with momentum 0.1 like the BatchNorm2d default.  Forward only (no backward here). */
+int opp_num_bn_layers(const opp_ctx* ctx);
+const char* opp_bn_layer_name(const opp_ctx* ctx, int i);      /* state-dict prefix, e.g. "backbone.layer1.0.bn1" */
+int opp_bn_layer_channels(const opp_ctx* ctx, int i);
+size_t opp_packed_train_weights_bytes(const opp_ctx* ctx);
+int opp_pack_train_weights(opp_ctx* ctx, const float* const* weights, int n_weights, void* packed,
+                           size_t packed_bytes, void* stream);
+size_t opp_backbone_train_workspace_bytes(const opp_ctx* ctx, int B, int H, int W);
+int opp_backbone_train(opp_ctx* ctx, const float* image, int B, int H, int W, float* feat_c, float* feat_f,
+                       float* bn_stats, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- stages ---------------------------------------------------------------------------- */
 size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W);
 /* ResNetFPN_8_2.forward (backbone/resnet.py:141-164).  image [H][W] in [0,1];

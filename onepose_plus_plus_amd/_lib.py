@@ -49,6 +49,13 @@ SIGNATURES = {
     "opp_num_weights": (c_int, [c_void_p]),
     "opp_weight_name": (c_char_p, [c_void_p, c_int]),
     "opp_weight_numel": (c_longlong, [c_void_p, c_int]),
+    "opp_num_bn_layers": (c_int, [c_void_p]),
+    "opp_bn_layer_name": (c_char_p, [c_void_p, c_int]),
+    "opp_bn_layer_channels": (c_int, [c_void_p, c_int]),
+    "opp_packed_train_weights_bytes": (c_size_t, [c_void_p]),
+    "opp_pack_train_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
+    "opp_backbone_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_backbone_train": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_packed_weights_bytes": (c_size_t, [c_void_p]),
     "opp_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     "opp_backbone_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

@@ -52,6 +52,13 @@ struct ConvDesc {  // one packed convolution
   float* w = nullptr;     // packed [cout_pad][ks*ks*cin_pad]
   float* bias = nullptr;  // [cout_pad] (folded BN shift) or nullptr
   float* h2s = nullptr;   // fp16x2 only: {scale, 1/scale} applied to w before the hi/lo split
+  // training mode (opp_pack_train_weights): the same packing WITHOUT the folded BatchNorm, plus the caller-owned
+  // affine parameters of the BatchNorm that follows this convolution
+  float* w_train = nullptr;
+  float* h2s_train = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  int bn_slot = -1;       // index of that BatchNorm among the backbone's BatchNorm layers (state-dict order)
   int cin_pad() const { return pad32(cin); }
   int cout_pad() const { return pad32(cout); }
   size_t w_floats() const { return (size_t)cout_pad() * ks * ks * cin_pad(); }
@@ -92,6 +99,9 @@ struct opp_ctx {
   int kpt_extent_n = 0;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
+  bool train_packed = false;
+  std::vector<std::string> bn_names;   // BatchNorm layers of the backbone in state-dict order (prefix, e.g. "backbone.bn1")
+  std::vector<int> bn_channels;
 };
 
 namespace {
@@ -110,6 +120,8 @@ int add_w(opp_ctx* c, const std::string& name, long long numel) {
   return (int)c->table.size() - 1;
 }
 int add_bn(opp_ctx* c, const std::string& p, int ch) {
+  c->bn_names.push_back(p);
+  c->bn_channels.push_back(ch);
   const int i = add_w(c, p + ".weight", ch);
   add_w(c, p + ".bias", ch);
   add_w(c, p + ".running_mean", ch);
@@ -130,11 +142,14 @@ BlockDesc mk_block(opp_ctx* c, const std::string& p, int cin, int cout, int stri
   b.conv1 = mk_conv(c, p + ".conv1.weight", cout, cin, 3);
   b.conv2 = mk_conv(c, p + ".conv2.weight", cout, cout, 3);
   b.conv1.bn_idx = add_bn(c, p + ".bn1", cout);
+  b.conv1.bn_slot = (int)c->bn_names.size() - 1;
   b.conv2.bn_idx = add_bn(c, p + ".bn2", cout);
+  b.conv2.bn_slot = (int)c->bn_names.size() - 1;
   if (stride != 1) {
     b.has_down = true;
     b.down = mk_conv(c, p + ".downsample.0.weight", cout, cin, 1);
     b.down.bn_idx = add_bn(c, p + ".downsample.1", cout);
+    b.down.bn_slot = (int)c->bn_names.size() - 1;
   }
   return b;
 }
@@ -195,6 +210,7 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   // --- same order as the reference state dict (backbone/resnet.py:88-124) ---
   c->stem = mk_conv(c, "backbone.conv1.weight", d0, 1, 7);
   c->stem.bn_idx = add_bn(c, "backbone.bn1", d0);
+  c->stem.bn_slot = (int)c->bn_names.size() - 1;
   c->blocks[0] = mk_block(c, "backbone.layer1.0", d0, d1, 1);
   c->blocks[1] = mk_block(c, "backbone.layer1.1", d1, d1, 1);
   c->blocks[2] = mk_block(c, "backbone.layer2.0", d1, d2, 2);
@@ -205,10 +221,12 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   c->l2_out = mk_conv(c, "backbone.layer2_outconv.weight", d3, d2, 1);
   c->l2_out2a = mk_conv(c, "backbone.layer2_outconv2.0.weight", d3, d3, 3);
   c->l2_out2a.bn_idx = add_bn(c, "backbone.layer2_outconv2.1", d3);
+  c->l2_out2a.bn_slot = (int)c->bn_names.size() - 1;
   c->l2_out2b = mk_conv(c, "backbone.layer2_outconv2.3.weight", d2, d3, 3);
   c->l1_out = mk_conv(c, "backbone.layer1_outconv.weight", d2, d1, 1);
   c->l1_out2a = mk_conv(c, "backbone.layer1_outconv2.0.weight", d2, d2, 3);
   c->l1_out2a.bn_idx = add_bn(c, "backbone.layer1_outconv2.1", d2);
+  c->l1_out2a.bn_slot = (int)c->bn_names.size() - 1;
   c->l1_out2b = mk_conv(c, "backbone.layer1_outconv2.3.weight", d1, d2, 3);
   if (cfg->kpt_enc_enable) {  // utils/position_encoding.py:62-79 -> encoder.{0,3,6,9}
     const int ch[5] = {3, cfg->kpt_enc_dims[0], cfg->kpt_enc_dims[1], cfg->kpt_enc_dims[2], cfg->coarse_d_model};
@@ -248,6 +266,13 @@ extern "C" const char* opp_weight_name(const opp_ctx* ctx, int i) {
 }
 extern "C" long long opp_weight_numel(const opp_ctx* ctx, int i) {
   return (ctx && i >= 0 && i < (int)ctx->table.size()) ? ctx->table[i].numel : -1;
+}
+extern "C" int opp_num_bn_layers(const opp_ctx* ctx) { return ctx ? (int)ctx->bn_names.size() : 0; }
+extern "C" const char* opp_bn_layer_name(const opp_ctx* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->bn_names.size()) ? ctx->bn_names[i].c_str() : nullptr;
+}
+extern "C" int opp_bn_layer_channels(const opp_ctx* ctx, int i) {
+  return (ctx && i >= 0 && i < (int)ctx->bn_names.size()) ? ctx->bn_channels[i] : -1;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -408,19 +433,77 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
 }
 
 // ----------------------------------------------------------------------------------------
+// training-mode weights: the backbone convolutions WITHOUT the folded BatchNorm
+// ----------------------------------------------------------------------------------------
+namespace {
+
+size_t plan_pack_train(opp_ctx* c, void* base) {
+  Arena a(base, (size_t)-1);
+  const int prec = gemm_prec(c->cfg);
+  const bool h2 = prec == OPP_PREC_FP16X2;
+  c->stem.w_train = a.f(split_floats((size_t)c->stem.cout * 64, prec));
+  c->stem.h2s_train = h2 ? a.f(2) : nullptr;
+  for (ConvDesc* d : all_convs(c)) {
+    if (d->bn_idx < 0) continue;      // no BatchNorm behind it: the eval packing is already the raw weight
+    d->w_train = a.f(split_floats(d->w_floats(), prec));
+    d->h2s_train = h2 ? a.f(2) : nullptr;
+  }
+  return opp_align(a.off);
+}
+
+}  // namespace
+
+extern "C" size_t opp_packed_train_weights_bytes(const opp_ctx* ctx) {
+  if (!ctx) return 0;
+  opp_ctx tmp = *ctx;
+  return plan_pack_train(&tmp, nullptr);
+}
+
+extern "C" int opp_pack_train_weights(opp_ctx* c, const float* const* w, int n, void* packed, size_t bytes, void* stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  OPP_CHECK_ARG(c && w && packed, "pack_train: null argument");
+  OPP_CHECK_ARG(c->packed, "pack_train: call opp_pack_weights first (the layers without BatchNorm share its packing)");
+  OPP_CHECK_ARG(n == (int)c->table.size(), "pack_train: expected %d weight tensors, got %d", (int)c->table.size(), n);
+  const size_t need = plan_pack_train(c, packed);
+  OPP_CHECK_ARG(bytes >= need, "pack_train: blob too small (%zu < %zu)", bytes, need);
+  const int prec = gemm_prec(c->cfg);
+  auto split = [&](float* wm, size_t nfl, float* sc) -> int {
+    if (prec == OPP_PREC_FP32) return OPP_OK;
+    if (prec == OPP_PREC_BF16X3) OPP_TRY(opp_b3_split(wm, c->scratch_h2, nfl, s));
+    else OPP_TRY(opp_h2_split(wm, c->scratch_h2, nfl, sc, s));
+    return copy_f(wm, c->scratch_h2, split_floats(nfl, prec), s);
+  };
+  OPP_TRY(opp_pack_stem(w[c->stem.w_idx], nullptr, c->stem.cout, c->stem.w_train, s));
+  OPP_TRY(split(c->stem.w_train, (size_t)c->stem.cout * 64, c->stem.h2s_train));
+  c->stem.gamma = w[c->stem.bn_idx];
+  c->stem.beta = w[c->stem.bn_idx + 1];
+  for (ConvDesc* d : all_convs(c)) {
+    if (d->bn_idx < 0) continue;
+    OPP_TRY(opp_pack_conv(w[d->w_idx], nullptr, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), d->w_train, s));
+    OPP_TRY(split(d->w_train, d->w_floats(), d->h2s_train));
+    d->gamma = w[d->bn_idx];          // caller-owned: must outlive the training forwards
+    d->beta = w[d->bn_idx + 1];
+  }
+  c->train_packed = true;
+  return OPP_OK;
+}
+
+// ----------------------------------------------------------------------------------------
 // backbone
 // ----------------------------------------------------------------------------------------
 namespace {
 
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
-             float* y, hipStream_t s, int h2, int tile_cfg = -1) {
+             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false) {
   OppGemm g;
   g.nonfinite = t_status_flag;
   g.conv = 1;
   g.prec = h2;
-  g.h2_inv = (h2 == OPP_PREC_FP16X2 && d.h2s) ? d.h2s + 1 : nullptr;
+  // raw = training mode: unfolded weights, no BatchNorm shift (bn_train applies the batch statistics afterwards)
+  const float* h2s = raw ? d.h2s_train : d.h2s;
+  g.h2_inv = (h2 == OPP_PREC_FP16X2 && h2s) ? h2s + 1 : nullptr;
   g.A0 = x;
-  g.Bn = 1;
+  g.Bn = Bn;
   g.Hin = Hin;
   g.Win = Win;
   g.Cin = d.cin_pad();
@@ -429,15 +512,15 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.pad = d.ks / 2;
   g.Hout = (Hin + 2 * g.pad - d.ks) / stride + 1;
   g.Wout = (Win + 2 * g.pad - d.ks) / stride + 1;
-  g.W = d.w;
+  g.W = raw ? d.w_train : d.w;
   g.K = d.ks * d.ks * d.cin_pad();
   g.ldw = (int)split_floats((size_t)g.K, h2);
-  g.M = g.Hout * g.Wout;
+  g.M = Bn * g.Hout * g.Wout;
   g.N = d.cout_pad();
   g.C = y;
   g.ldc = d.cout_pad();
   g.n_store = d.cout_pad();
-  g.bias = d.bias;
+  g.bias = raw ? nullptr : d.bias;
   g.res_mode = res_mode;
   g.R = res;
   g.ldr = d.cout_pad();
@@ -546,6 +629,126 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
 }
 
 }  // namespace
+
+namespace {
+
+// ---- training mode: ResNetFPN_8_2.forward with BatchNorm batch statistics, B images per call ----------------
+size_t plan_backbone_train(const opp_ctx* c, int B, int H, int W, Arena& a, BackboneBufs& b, float** raw, void** bn_scratch) {
+  const size_t p2 = (size_t)B * (H / 2) * (W / 2), p4 = (size_t)B * (H / 4) * (W / 4), p8 = (size_t)B * (H / 8) * (W / 8);
+  const int c1 = pad32(c->cfg.block_dims[0]), c2 = pad32(c->cfg.block_dims[1]), c3 = pad32(c->cfg.block_dims[2]);
+  b.col = a.f(p2 * 64);
+  b.x0 = a.f(p2 * c1);
+  b.t1 = a.f(p2 * c1);
+  b.x1a = a.f(p2 * c1);
+  b.x1 = a.f(p2 * c1);
+  b.t2 = a.f(p4 * c2);
+  b.ds2 = a.f(p4 * c2);
+  b.x2a = a.f(p4 * c2);
+  b.x2 = a.f(p4 * c2);
+  b.t3 = a.f(p8 * c3);
+  b.ds3 = a.f(p8 * c3);
+  b.x3a = a.f(p8 * c3);
+  b.x3 = a.f(p8 * c3);
+  b.l2 = a.f(p4 * c3);
+  b.u2 = a.f(p4 * c3);
+  b.x2o = a.f(p4 * c2);
+  b.l1 = a.f(p2 * c2);
+  b.u1 = a.f(p2 * c2);
+  size_t mx = p2 * (size_t)(c1 > c2 ? c1 : c2);
+  mx = p4 * c3 > mx ? p4 * c3 : mx;
+  *raw = a.f(mx);                                        // raw convolution output ahead of each BatchNorm
+  *bn_scratch = a.raw(opp_bn_train_scratch_bytes((int)p2, 256));
+  return a.off;
+}
+
+int backbone_train_impl(opp_ctx* c, const float* image, int B, int H, int W, float* feat_c, float* feat_f, float* bn_stats,
+                        Arena& a, hipStream_t s) {
+  OPP_CHECK_ARG(c && c->packed && c->train_packed, "backbone_train: training weights not packed (opp_pack_train_weights)");
+  OPP_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone_train: bad B / H / W (%d, %dx%d)", B, H, W);
+  BackboneBufs b;
+  float* raw;
+  void* scratch;
+  plan_backbone_train(c, B, H, W, a, b, &raw, &scratch);
+  if (!a.ok) {
+    opp_set_error("backbone_train: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  const int hp = gemm_prec(c->cfg);
+  const float eps = 1e-5f;
+  // conv -> BatchNorm(batch statistics) -> (+ residual) -> activation   (resnet.py:37-45, :143, :153, :157)
+  auto conv_bn = [&](const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int act, float* y) -> int {
+    const int Ho = (Hin + 2 * (d.ks / 2) - d.ks) / stride + 1, Wo = (Win + 2 * (d.ks / 2) - d.ks) / stride + 1;
+    OPP_TRY(run_conv(x, Hin, Win, d, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, raw, s, hp, -1, B, true));
+    return opp_bn_train(raw, B * Ho * Wo, d.cout_pad(), d.cout, d.gamma, d.beta, eps, res, act, y,
+                        bn_stats ? bn_stats + (size_t)d.bn_slot * 512 : nullptr, scratch, s);
+  };
+  auto block = [&](const float* x, int Hin, int Win, const BlockDesc& bd, int stride, float* tmp, float* ds, float* y) -> int {
+    const int Ho = Hin / stride, Wo = Win / stride;
+    OPP_TRY(conv_bn(x, Hin, Win, bd.conv1, stride, nullptr, OPP_ACT_RELU, tmp));
+    const float* shortcut = x;
+    if (bd.has_down) {
+      OPP_TRY(conv_bn(x, Hin, Win, bd.down, stride, nullptr, OPP_ACT_NONE, ds));
+      shortcut = ds;
+    }
+    return conv_bn(tmp, Ho, Wo, bd.conv2, 1, shortcut, OPP_ACT_RELU, y);
+  };
+  OPP_TRY(opp_stem_im2col(image, B, H, W, b.col, s));
+  {
+    OppGemm g;
+    g.nonfinite = t_status_flag;
+    g.A0 = b.col;
+    g.lda0 = 64;
+    g.ksplit = 64;
+    g.W = c->stem.w_train;
+    g.ldw = (int)split_floats(64, hp);
+    g.M = B * H2 * W2;
+    g.N = c->stem.cout;
+    g.K = 64;
+    g.C = raw;
+    g.ldc = pad32(c->stem.cout);
+    g.n_store = pad32(c->stem.cout);
+    g.prec = hp;
+    g.h2_inv = hp == OPP_PREC_FP16X2 ? c->stem.h2s_train + 1 : nullptr;
+    OPP_TRY(opp_gemm_launch(g, s));
+    OPP_TRY(opp_bn_train(raw, B * H2 * W2, pad32(c->stem.cout), c->stem.cout, c->stem.gamma, c->stem.beta, eps, nullptr, OPP_ACT_RELU,
+                         b.x0, bn_stats ? bn_stats + (size_t)c->stem.bn_slot * 512 : nullptr, scratch, s));
+  }
+  OPP_TRY(block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a));
+  OPP_TRY(block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1));
+  OPP_TRY(block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a));
+  OPP_TRY(block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2));
+  OPP_TRY(block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a));
+  OPP_TRY(block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3));
+  // FPN: the laterals and the last convolutions have no BatchNorm -> same kernels as in eval mode, batched
+  OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp, -1, B));
+  OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp, -1, B));
+  OPP_TRY(conv_bn(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_ACT_LEAKY, b.u2));
+  OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp, -1, B));
+  OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp, -1, B));
+  OPP_TRY(conv_bn(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_ACT_LEAKY, b.u1));
+  OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp, -1, B));
+  return OPP_OK;
+}
+
+}  // namespace
+
+extern "C" size_t opp_backbone_train_workspace_bytes(const opp_ctx* ctx, int B, int H, int W) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  BackboneBufs b;
+  float* raw;
+  void* sc;
+  return opp_align(plan_backbone_train(ctx, B, H, W, a, b, &raw, &sc)) + 256;
+}
+
+extern "C" int opp_backbone_train(opp_ctx* ctx, const float* image, int B, int H, int W, float* feat_c, float* feat_f,
+                                  float* bn_stats, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
+  OPP_CHECK_ARG(ctx && image && feat_c && feat_f && ws, "backbone_train: null argument");
+  Arena a(ws, ws_bytes);
+  return backbone_train_impl(ctx, image, B, H, W, feat_c, feat_f, bn_stats, a, (hipStream_t)stream);
+}
 
 extern "C" size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W) {
   if (!ctx) return 0;

@@ -54,7 +54,7 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __res
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cout * 64) return;
   const int co = i >> 6, k = i & 63;
-  out[i] = k < 49 ? w[co * 49 + k] * scale[co] : 0.f;
+  out[i] = k < 49 ? w[co * 49 + k] * (scale ? scale[co] : 1.f) : 0.f;
 }
 
 // im2col of the 1-channel image for the 7x7 stride-2 pad-3 stem (resnet.py:101,143):

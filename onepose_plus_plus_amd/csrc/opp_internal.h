@@ -50,6 +50,11 @@ int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream
 int opp_b3_split(const float* in, float* out, size_t n, hipStream_t stream);
 int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
 int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream);
+// bn_train.hip: training-mode BatchNorm (batch statistics) over an NHWC tensor [rows][ld] with C real channels:
+// out = act((y - mean_batch) * invstd_batch * gamma + beta (+ res)); stat_out [2][C] = batch mean, unbiased variance
+size_t opp_bn_train_scratch_bytes(int rows, int ld);
+int opp_bn_train(const float* y, int rows, int ld, int C, const float* gamma, const float* beta, float eps, const float* res,
+                 int act, float* out, float* stat_out, void* scratch, hipStream_t stream);
 // kpt.hip
 int opp_kpt_stats(const float* kpts, int n, float* stats, hipStream_t stream);
 int opp_kpt_encode(const float* kpts, const float* stats, const float* bank, int n, const float* const* wt,

@@ -30,8 +30,18 @@ LN_EPS = 1e-5  # nn.LayerNorm / nn.InstanceNorm1d default
 # --------------------------------------------------------------------------------------
 # backbone: backbone/resnet.py:85-164 (ResNetFPN_8_2) + BasicBlock :20-45
 # --------------------------------------------------------------------------------------
+_TRAIN = {"on": False}     # set by forward(training=True): BatchNorm2d uses batch statistics and updates `sd` in place
+
+
 def _bn(sd, p, x):
-    # eval-mode BatchNorm2d: running statistics (resnet.py:25-26, :102)
+    # BatchNorm2d (resnet.py:25-26, :102).  eval: running statistics.  train(): statistics of the current batch over
+    # (B, H, W), running_mean / running_var updated with momentum 0.1 (unbiased variance), num_batches_tracked += 1 --
+    # exactly torch.nn.BatchNorm2d's defaults, which is what the reference constructs.
+    if _TRAIN["on"]:
+        y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                         True, 0.1, BN_EPS)
+        sd[p + ".num_batches_tracked"] += 1
+        return y
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
 
@@ -201,12 +211,30 @@ def coarse_match_select(conf, hw_c, thr, border_rm):
     return b_ids, i_ids, j_ids, conf[b_ids, i_ids, j_ids]
 
 
-def coarse_matching(feat3d, feat2d, data, ccfg, mask_query=None):
-    """utils/coarse_matching.py:76-123 + :219-242 (inference: no training padding)."""
+def coarse_matching(feat3d, feat2d, data, ccfg, mask_query=None, training=False, randint=torch.randint):
+    """utils/coarse_matching.py:76-123 + :219-242; training=True adds the padding branch :177-217 (sub-sample the
+    predicted matches, pad with ground-truth pairs of `conf_matrix_gt`; random draws from `randint`)."""
     conf = dual_softmax_conf(feat3d, feat2d, ccfg["dual_softmax"]["temperature"], mask_query)
     data["conf_matrix"] = conf
     hw_c = data["q_hw_c"]
     b_ids, i_ids, j_ids, mconf = coarse_match_select(conf, hw_c, ccfg["thr"], ccfg["border_rm"])
+    if training and ccfg["train"]["train_padding"]:
+        B, N, L = conf.shape
+        max_train = int(B * min(N, L) * ccfg["train"]["train_coarse_percent"])
+        pad_min = ccfg["train"]["train_pad_num_gt_min"]
+        n_pred = len(b_ids)
+        assert pad_min < max_train
+        if n_pred <= max_train - pad_min:
+            pred_idx = torch.arange(n_pred)
+        else:
+            pred_idx = randint(n_pred, (max_train - pad_min,))
+        spv_b, spv_i, spv_j = torch.where(data["conf_matrix_gt"])
+        assert len(spv_b) != 0
+        gt_idx = randint(len(spv_b), (max(max_train - n_pred, pad_min),))
+        b_ids = torch.cat([b_ids[pred_idx], spv_b[gt_idx]])
+        i_ids = torch.cat([i_ids[pred_idx], spv_i[gt_idx]])
+        j_ids = torch.cat([j_ids[pred_idx], spv_j[gt_idx]])
+        mconf = torch.cat([mconf[pred_idx], torch.zeros(len(gt_idx))])
     scale = data["q_hw_i"][0] / hw_c[0]
     if "query_image_scale" in data:
         scale = scale * data["query_image_scale"][b_ids][:, [1, 0]]
@@ -269,8 +297,18 @@ def fine_matching(feat3d, win, data):
 _PE_CACHE = {}
 
 
-def forward(sd, data, cfg, keep_intermediates=False):
-    """Mutates `data` in place like the reference.  Inference (eval, no_grad) only."""
+def forward(sd, data, cfg, keep_intermediates=False, training=False, randint=torch.randint):
+    """Mutates `data` in place like the reference.  Forward only (no_grad).  training=True restates the module in
+    train() mode: BatchNorm batch statistics (+ running statistics of `sd` updated IN PLACE) and the training
+    branch of get_coarse_match."""
+    _TRAIN["on"] = bool(training)
+    try:
+        return _forward(sd, data, cfg, keep_intermediates, training, randint)
+    finally:
+        _TRAIN["on"] = False
+
+
+def _forward(sd, data, cfg, keep_intermediates, training, randint):
     with torch.no_grad():
         img = data["query_image"]
         data.update(bs=img.size(0), q_hw_i=img.shape[2:])
@@ -291,7 +329,7 @@ def forward(sd, data, cfg, keep_intermediates=False):
                                            tokens2d, qmask)                             # :160-164
         if keep_intermediates:
             data.update(_feat_c_tokens=tokens2d, _feat_f=feat_f, _f3=f3, _f2=f2)
-        coarse_matching(f3, f2, data, cfg["coarse_matching"], qmask)                    # :167
+        coarse_matching(f3, f2, data, cfg["coarse_matching"], qmask, training, randint)  # :167
         if not cfg["fine_matching"]["enable"]:                                          # :169-176
             data["mkpts_query_f"] = data["mkpts_query_c"]
             return

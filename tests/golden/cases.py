@@ -47,3 +47,12 @@ BATCH_CASES = {
     "e2e_b2_mask_64x96_n200": ((64, 96), 200, 0.0, 0, [3, 4], True),
     "e2e_b3_128x128_n300": ((128, 128), 300, 0.0, 0, [1, 5, 6], False),
 }
+
+# train()-mode forward (BatchNorm batch statistics + running-stat update, training branch of get_coarse_match with
+# ground-truth padding): name -> (hw, n_points, thr, weight_seed, [input seeds], n_gt_per_sample,
+#                                 train_coarse_percent, train_pad_num_gt_min)
+TRAIN_CASES = {
+    "train_b2_128x128_n300": ((128, 128), 300, 0.0, 0, [1, 5], 60, 0.3, 20),          # all predictions kept + gt padding
+    "train_b2_128x128_n300_sub": ((128, 128), 300, 0.0, 0, [1, 5], 60, 0.05, 20),     # predictions sub-sampled (randint)
+    "train_b4_64x96_n150": ((64, 96), 150, 0.0, 7, [2, 3, 4, 9], 30, 0.3, 10),        # B = 4 like train.yaml:185
+}

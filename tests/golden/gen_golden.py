@@ -20,7 +20,8 @@ from oracle.refload import load_reference_model_class, load_reference_modules  #
 from onepose_plus_plus_amd.config import default_config  # noqa: E402
 from onepose_plus_plus_amd.synthetic import (make_state_dict, make_inputs,  # noqa: E402
                                              make_planted_matcher_inputs, make_fine_ids)
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES  # noqa: E402
+from tests.golden.cases import (E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES,  # noqa: E402
+                                BATCH_CASES, TRAIN_CASES)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -159,6 +160,48 @@ def gen_batch():
         print(name, "M =", len(data["mconf"]), "per sample:", torch.bincount(data["b_ids"], minlength=int(data["bs"])).tolist())
 
 
+def gen_train():
+    """The reference module in train() mode (what PL_OnePosePlus.training_step runs, lightning_model:54-81), forward
+    only: BatchNorm batch statistics + running-statistics update, training branch of get_coarse_match.  The
+    torch.randint draws of that branch are recorded and stored, so that other implementations can replay them."""
+    from tests.helpers import train_setup
+    cls = load_reference_model_class()
+    for name in TRAIN_CASES:
+        cfg, sd, data = train_setup(name)
+        model = cls(cfg)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        draws = []
+        real = torch.randint
+
+        def rec(*a, **kw):
+            d = real(*a, **kw)
+            draws.append(d.clone())
+            return d
+        torch.manual_seed(123)
+        torch.randint = rec
+        try:
+            with torch.no_grad():
+                model(data)
+        finally:
+            torch.randint = real
+        out = {}
+        for k in ["b_ids", "i_ids", "j_ids", "gt_mask", "m_bids", "mkpts_3d_db", "mkpts_query_c", "mconf", "expec_f",
+                  "mkpts_query_f"]:
+            out[k] = data[k].numpy()
+        out.update(conf_digest_batched(data["conf_matrix"]))
+        out["meta"] = np.array([data["bs"], *data["q_hw_i"], *data["q_hw_c"], *data["q_hw_f"], data.get("W", -1)], dtype=np.int64)
+        for i, d in enumerate(draws):
+            out["randint_%d" % i] = d.numpy()
+        out["n_randint"] = np.array(len(draws))
+        after = model.state_dict()
+        for k, v in after.items():          # running statistics after ONE training forward
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                out["bn/" + k] = v.numpy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "M' =", len(data["b_ids"]), "M =", len(data["mconf"]), "draws", [tuple(d.shape) for d in draws])
+
+
 def gen_e2e():
     cls = load_reference_model_class()
     for name, (hw, n, thr, wseed, iseed, fine) in E2E_CASES.items():
@@ -252,7 +295,8 @@ if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count())
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     steps = {"stages": gen_stage_features, "matcher": gen_matcher, "fine": gen_fine, "e2e": gen_e2e,
-             "transformer": gen_transformer, "highconf": gen_highconf, "batch": gen_batch}
+             "transformer": gen_transformer, "highconf": gen_highconf, "batch": gen_batch,
+             "train": gen_train}
     for k, fn in steps.items():
         if not only or k in only:
             fn()

@@ -7,7 +7,8 @@ import torch
 from onepose_plus_plus_amd.config import default_config
 from onepose_plus_plus_amd.synthetic import (make_state_dict, make_inputs,
                                              make_planted_matcher_inputs, make_fine_ids)
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES
+from tests.golden.cases import (E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES,
+                                TRAIN_CASES)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -51,6 +52,37 @@ def batch_setup(name):
         m[1, hc - 2:, :] = 0            # bottom padding of sample 1
         data["query_image_mask"] = m
     return cfg, sd, data
+
+
+def train_setup(name):
+    """-> cfg, sd, data of a train()-mode case (incl. `conf_matrix_gt` [B,N,L] int16 with planted ground-truth pairs)"""
+    hw, n, thr, wseed, seeds, n_gt, pct, pad_min = TRAIN_CASES[name]
+    cfg = default_config(thr=thr)
+    cfg["coarse_matching"]["train"] = {"train_padding": True, "train_coarse_percent": pct, "train_pad_num_gt_min": pad_min}
+    sd = make_state_dict(cfg, wseed)
+    parts = [make_inputs(n, hw, sd_) for sd_ in seeds]
+    data = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    B, L = len(seeds), (hw[0] // 8) * (hw[1] // 8)
+    data["query_image_scale"] = torch.tensor([[1.0 + 0.25 * (b % 2), 1.0 - 0.125 * (b % 3)] for b in range(B)])
+    g = torch.Generator().manual_seed(1000 + wseed)
+    gt = torch.zeros(B, n, L, dtype=torch.int16)
+    for b in range(B):
+        gt[b, torch.randperm(n, generator=g)[:n_gt], torch.randperm(L, generator=g)[:n_gt]] = 1
+    data["conf_matrix_gt"] = gt
+    return cfg, sd, data
+
+
+class RecordedRandint:
+    """stands in for torch.randint in the training branch of get_coarse_match: replays the draws recorded when the
+    reference produced the fixture (the draws themselves are device / generator specific, coarse_matching.py:192-204)"""
+
+    def __init__(self, draws):
+        self.draws = [torch.as_tensor(d) for d in draws]
+
+    def __call__(self, high, size, device=None, **kw):
+        d = self.draws.pop(0)
+        assert tuple(d.shape) == tuple(size) and (d.numel() == 0 or int(d.max()) < high), (d.shape, size, high)
+        return d.to(device) if device is not None else d
 
 
 def highconf_geometry(name):
@@ -173,6 +205,25 @@ def assert_batched_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol
     assert_match_outputs({k: v for k, v in got.items() if k != "conf_matrix"}, rest, tol_conf, tol_off, tol_px, where)
     meta = gold["meta"]
     assert got["bs"] == meta[0] and tuple(got["q_hw_i"]) == tuple(meta[1:3]) and tuple(got["q_hw_c"]) == tuple(meta[3:5])
+
+
+def assert_train_outputs(got, state, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_px=TOL_PIXEL, tol_bn=1e-4, where=""):
+    """train()-mode forward: matches / confidences / fine offsets like the batched case (M' padded rows, M predicted
+    ones) + the BatchNorm running statistics after the forward (`state`: name -> tensor)."""
+    assert_batched_outputs(got, {k: v for k, v in gold.items() if not k.startswith(("bn/", "randint_", "n_randint"))},
+                           tol_conf, tol_off, tol_px, where)
+    assert len(gold["b_ids"]) > len(gold["mconf"]) > 0          # ground-truth padding present
+    n = 0
+    for k, v in gold.items():
+        if k.startswith("bn/"):
+            t = to_np(state[k[3:]])
+            if k.endswith("num_batches_tracked"):
+                assert int(t) == int(v), (where, k)
+            else:
+                err = np.abs(t - v).max()
+                assert err <= tol_bn * max(1.0, float(np.abs(v).max())), (where, k, float(err))
+            n += 1
+    assert n == 3 * 17          # 17 BatchNorm layers: stem, 2 + 2 + 3 + 2 + 3 + 2 in the blocks, 2 in the FPN heads
 
 
 def assert_transformer_digest(got, gold, rel, where=""):

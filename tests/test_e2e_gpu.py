@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES, HIGHCONF_CASES, BATCH_CASES
+from tests.golden.cases import E2E_CASES, HIGHCONF_CASES, BATCH_CASES, TRAIN_CASES
 
 pytestmark = pytest.mark.gpu
 
@@ -74,6 +74,34 @@ def test_batched_masked_vs_golden(name, precision):
         conf = out["conf_matrix"].cpu()
         assert (conf.transpose(1, 2)[~m] == 0).all()
         assert m[out["b_ids"].cpu(), out["j_ids"].cpu()].all()
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name", list(TRAIN_CASES))
+def test_train_mode_forward_vs_golden(name, precision):
+    """`model.train(); model(batch)` (forward of PL_OnePosePlus.training_step, lightning_model:54-81) on the HIP path
+    against the reference module in train() mode: BatchNorm batch statistics over the B images, running statistics
+    after the step, materialised conf_matrix, training branch of get_coarse_match (predictions + ground-truth
+    padding, the reference's recorded torch.randint draws replayed), fine level on the padded list."""
+    from tests import hip_ops as ops
+    cfg, sd, data = H.train_setup(name)
+    gold = H.load_golden(name)
+    model = ops.make_model(cfg, sd, precision)
+    model.train()
+    model.train_randint = H.RecordedRandint([gold["randint_%d" % i] for i in range(int(gold["n_randint"]))])
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    with pytest.raises(RuntimeError, match="no backward"):      # gradients are not available yet: loud, not silent
+        model(dict(d))
+    with torch.no_grad():
+        model(d)
+    torch.cuda.synchronize()
+    H.assert_train_outputs(d, model.state_dict(), gold, tol_bn=1e-4, where=name)
+    assert d["gt_mask"].sum().item() == len(gold["b_ids"]) - len(gold["mconf"])
+    # the step moved the running statistics: the same module in eval() now differs from a fresh one
+    model.eval()
+    e1 = ops.run_model(model, {k: v[:1] for k, v in data.items() if k != "conf_matrix_gt"})
+    e0 = ops.run_model(ops.make_model(cfg, sd, precision), {k: v[:1] for k, v in data.items() if k != "conf_matrix_gt"})
+    assert not torch.equal(e0["conf_matrix"], e1["conf_matrix"])
 
 
 def test_worker_flow_recovers_pose():

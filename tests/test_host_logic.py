@@ -97,7 +97,7 @@ def test_unsupported_config_values_raise_like_reference():
 
 def test_inference_only_and_no_cpu_fallback():
     m = OnePosePlus_model(default_config())
-    with pytest.raises(RuntimeError, match="inference-only"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # train() mode included
         m({"query_image": torch.zeros(1, 1, 64, 64)})
     m.eval()
     with pytest.raises(RuntimeError, match="no CPU fallback"):

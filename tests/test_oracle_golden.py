@@ -8,7 +8,8 @@ import torch
 from oracle import onepose_oracle as O
 from oracle.refload import reference_available, load_reference_model_class
 from tests import helpers as H
-from tests.golden.cases import E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES
+from tests.golden.cases import (E2E_CASES, MATCHER_CASES, FINE_CASES, TRANSFORMER_CASES, HIGHCONF_CASES, BATCH_CASES,
+                                TRAIN_CASES)
 
 SMALL_E2E = [n for n in E2E_CASES if "512" not in n]
 
@@ -76,6 +77,18 @@ def test_oracle_batched_masked_vs_golden(name):
     cfg, sd, data = H.batch_setup(name)
     O.forward(sd, data, cfg)
     H.assert_batched_outputs(data, H.load_golden(name), tol_conf=2e-5, tol_off=5e-5, tol_px=2e-4, where=name)
+
+
+@pytest.mark.parametrize("name", list(TRAIN_CASES))
+def test_oracle_train_mode_vs_golden(name):
+    """train()-mode forward: BatchNorm batch statistics + running-statistics update, training branch of
+    get_coarse_match with the reference's recorded random draws."""
+    cfg, sd, data = H.train_setup(name)
+    gold = H.load_golden(name)
+    draws = [gold["randint_%d" % i] for i in range(int(gold["n_randint"]))]
+    sd = {k: v.clone() for k, v in sd.items()}
+    O.forward(sd, data, cfg, training=True, randint=H.RecordedRandint(draws))
+    H.assert_train_outputs(data, sd, gold, tol_conf=2e-5, tol_off=5e-5, tol_px=2e-4, tol_bn=1e-5, where=name)
 
 
 @pytest.mark.parametrize("name", list(MATCHER_CASES))
