@@ -1,0 +1,103 @@
+"""GPU: the multi-process paths of bench.py / per-object sharding on real devices.
+
+  * world_size 1 over nccl (= RCCL) through the SAME self-launch code path `python bench.py --gpus N` takes (runs on
+    the 1-GPU box): the launcher starts torch.distributed.run, the rank initialises the process group, broadcasts
+    the weights and reports `n_ranks_seen` / per-rank devices;
+  * world_size 2 over nccl when at least two devices are visible (skipped otherwise): weights broadcast from rank 0,
+    every rank matches its own object, results gathered -- must equal the single-process results bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, env_extra=None):
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-seconds", "0",
+                        "--no-roofline", "--no-legs", "--hw", "128", "--n-points", "300"] + extra,
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_plain_and_torchrun_paths_agree():
+    plain = _run_bench(["--gpus", "1"])
+    assert plain["n_gpus"] == 1 and plain["config"]["n_ranks_seen"] == 1 and plain["value"] > 0
+    # the N > 1 launcher path, exercised with N = 1: RANK / WORLD_SIZE set by torch.distributed.run, RCCL process group
+    port = str(29000 + os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--cpu-seconds", "0", "--no-roofline", "--no-legs", "--hw", "128", "--n-points", "300"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tr = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert tr["config"]["n_ranks_seen"] == 1 and tr["config"]["rank_devices"][0]["rank"] == 0
+    assert tr["value"] > 0 and tr["n_gpus"] == 1 and tr["scaling"] == "weak"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+def test_bench_self_launch_two_ranks():
+    out = _run_bench(["--gpus", "2"])
+    assert out["n_gpus"] == 2 and out["config"]["n_ranks_seen"] == 2
+    devs = sorted(d["device"] for d in out["config"]["rank_devices"])
+    assert devs == [0, 1] and len({d["pid"] for d in out["config"]["rank_devices"]}) == 2
+
+
+def _nccl_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd.sharding import broadcast_weights
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cfg = default_config(thr=0.0)
+        model = OnePosePlus_model(cfg).eval().to(dev)
+        broadcast_weights(model, make_state_dict(cfg, 0) if rank == 0 else None, src=0)
+        d = {k: v.to(dev) for k, v in make_inputs(300, (128, 128), 10 + rank).items()}
+        with torch.no_grad():
+            model(d)
+        torch.cuda.synchronize(dev)
+        q.put((rank, d["i_ids"].cpu(), d["j_ids"].cpu(), d["mconf"].cpu()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+def test_sharded_objects_over_rccl_match_single_process():
+    import torch.multiprocessing as mp
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() + 7) % 2000
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, i, j, c = q.get(timeout=600)
+        res[r] = (i, j, c)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = default_config(thr=0.0)
+    single = ops.make_model(cfg, make_state_dict(cfg, 0))
+    for r in range(2):
+        out = ops.run_model(single, make_inputs(300, (128, 128), 10 + r))
+        assert torch.equal(out["i_ids"].cpu(), res[r][0]) and torch.equal(out["j_ids"].cpu(), res[r][1])
+        assert torch.equal(out["mconf"].cpu(), res[r][2])
