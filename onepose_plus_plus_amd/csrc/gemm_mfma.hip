@@ -1024,6 +1024,11 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
     case 293: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
     case 294: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 94>(g, stream) : OPP_ERR_INVALID;   // no LDS fragment reads
     case 295: return (g.conv && h3) ? launch_timed<128, 128, 4, 2, OPP_PREC_BF16X3, 95>(g, stream) : OPP_ERR_INVALID;   // no split arithmetic
+    case 391: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 91>(g, stream) : OPP_ERR_INVALID;   // 256x128: no global loads
+    case 392: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores / split
+    case 393: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
+    case 394: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 94>(g, stream) : OPP_ERR_INVALID;   // no LDS fragment reads
+    case 395: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 95>(g, stream) : OPP_ERR_INVALID;   // no split arithmetic
     case 191: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 91>(g, stream) : OPP_ERR_INVALID;   // no global loads
     case 192: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores
     case 193: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
@@ -1117,7 +1122,15 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
                                    {2, 64, 64, 3, 1000, 9000}};
       const long long nk = g.K / 32, cus = 256;
       long long best = -1;
+#ifdef OPP_TUNING
+      static const int only_env = getenv("OPP_B3_ONLY_CFG") ? atoi(getenv("OPP_B3_ONLY_CFG")) : -1;   // tuning: force one tile
+      static const int skip_env = getenv("OPP_B3_SKIP_BIG") ? atoi(getenv("OPP_B3_SKIP_BIG")) : 0;    // tuning: no 160 KB tiles
+#endif
       for (const Cand& c : cands) {
+#ifdef OPP_TUNING
+        if (only_env >= 0 && c.cfg != only_env && !(c.cfg == 2 && only_env != 2 && (long long)opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 64) <= 256)) continue;
+        if (skip_env && (c.cfg == 20 || c.cfg == 22)) continue;
+#endif
         if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
         const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
         const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;

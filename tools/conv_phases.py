@@ -11,8 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from onepose_plus_plus_amd import _lib  # noqa: E402
 
-CASES = [("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1), ("l1_out2a 3x3 196->196 @256", 256, 256, 224, 224, 3, 1),
-         ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1), ("layer3 3x3 256->256 @64", 64, 64, 256, 256, 3, 1)]
+CASES = [("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1), ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1)]
 
 
 def main():
@@ -36,7 +35,8 @@ def main():
         bias = torch.randn(cout, device="cuda")
         variants = {0: ((120, 256, 128, 8), (121, 128, 128, 4), (122, 128, 128, 8)),
                     1: ((120, 256, 128, 8), (121, 128, 128, 4), (122, 128, 128, 8), (191, 256, 128, 8), (192, 256, 128, 8), (193, 256, 128, 8)),
-                    2: ((122, 128, 128, 8), (291, 128, 128, 8), (292, 128, 128, 8), (293, 128, 128, 8), (294, 128, 128, 8), (295, 128, 128, 8))}[args.prec]
+                    2: ((122, 128, 128, 8), (291, 128, 128, 8), (292, 128, 128, 8), (293, 128, 128, 8), (294, 128, 128, 8), (295, 128, 128, 8),
+                        (120, 256, 128, 8), (391, 256, 128, 8), (392, 256, 128, 8), (393, 256, 128, 8), (394, 256, 128, 8), (395, 256, 128, 8))}[args.prec]
         for cfg, bm, bn, waves in variants:
             nb = -(-(H // stride) * (W // stride) // bm) * -(-cout // bn)
             ts = torch.zeros(nb * waves * 4, dtype=torch.int64, device="cuda")
