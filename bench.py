@@ -161,9 +161,11 @@ def run(args):
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
+    policy = "throughput" if n_streams > 1 else "latency"     # tile choice for several forwards in flight (opp_config.tile_policy)
+    model.set_tile_policy(policy)
     models = [model]
     for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
-        m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).to(dev)
+        m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).set_tile_policy(policy).to(dev)
         m.load_state_dict(model.state_dict(), strict=True)
         models.append(m)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
@@ -291,7 +293,7 @@ def run(args):
                                    "matches on these random weights (the conf matrix is still fully materialised)"
                                    % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams,
                                       args.thr, matches_last),
-                       "streams_per_gpu": n_streams, "gemm_precision": precision,
+                       "streams_per_gpu": n_streams, "gemm_precision": precision, "tile_policy": policy,
                        "matches_last_step": matches_last, "object_token_cache": True,
                        "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
                        "model_gflop_per_image": round(flops_img / 1e9, 1),

@@ -61,6 +61,11 @@ typedef struct opp_config {
    *     absolute 2^-25 error; weights are pre-scaled per matrix and unrestricted.  The coarse score GEMM stays fp32.
    * 2 = as 1, and the score GEMM runs on the fp16x2 path too (image tokens split once per image). */
   int gemm_precision;
+  /* Not a reference key: what the automatic GEMM / conv tile choice minimises.  0 = the duration of each launch
+   * (one forward at a time: lowest latency); 1 = the CU time each launch occupies (several forwards in flight on
+   * separate streams -- MatcherPool, bench.py --streams > 1 -- where other forwards' kernels fill idle CUs: +3.5...6.5 %
+   * images/s with three forwards in flight, -9 % for a forward running alone).  Results are bit-identical. */
+  int tile_policy;
 } opp_config;
 
 typedef struct opp_ctx opp_ctx;

@@ -33,6 +33,7 @@ class OppConfig(Structure):
         ("match_border_rm", c_int),
         ("match_temperature", c_float),
         ("gemm_precision", c_int),
+        ("tile_policy", c_int),
     ]
 
 

@@ -109,10 +109,18 @@ namespace {
 // fp16x2 range guard: the status flag of the ctx whose stage this host thread is enqueuing (every OppGemm
 // built below picks it up)
 thread_local int* t_status_flag = nullptr;
+thread_local int t_tile_policy = OPP_TILES_LATENCY;   // opp_config.tile_policy of that ctx
 struct FlagScope {
   int* prev;
-  explicit FlagScope(const opp_ctx* c) : prev(t_status_flag) { t_status_flag = c ? c->status_flag : nullptr; }
-  ~FlagScope() { t_status_flag = prev; }
+  int prev_policy;
+  explicit FlagScope(const opp_ctx* c) : prev(t_status_flag), prev_policy(t_tile_policy) {
+    t_status_flag = c ? c->status_flag : nullptr;
+    t_tile_policy = c ? c->cfg.tile_policy : OPP_TILES_LATENCY;
+  }
+  ~FlagScope() {
+    t_status_flag = prev;
+    t_tile_policy = prev_policy;
+  }
 };
 
 int add_w(opp_ctx* c, const std::string& name, long long numel) {
@@ -203,6 +211,8 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
                     cfg->fine_n_layers <= OPP_MAX_LAYERS, "too many transformer layers");
   OPP_CHECK_ARG(!cfg->kpt_enc_enable || (cfg->kpt_enc_dims[0] == 32 && cfg->kpt_enc_dims[1] == 64 && cfg->kpt_enc_dims[2] == 128),
                 "keypoint encoder must be [32,64,128]");
+  OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
+  OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
   OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
   opp_ctx* c = new opp_ctx();
   c->cfg = *cfg;
@@ -497,6 +507,7 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
              float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false) {
   OppGemm g;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.conv = 1;
   g.prec = h2;
   // raw = training mode: unfolded weights, no BatchNorm shift (bn_train applies the batch statistics afterwards)
@@ -593,7 +604,9 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
   {
     OppGemm g;
     g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
     g.A0 = b.col;
     g.lda0 = 64;
     g.ksplit = 64;
@@ -697,6 +710,7 @@ int backbone_train_impl(opp_ctx* c, const float* image, int B, int H, int W, flo
   {
     OppGemm g;
     g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
     g.A0 = b.col;
     g.lda0 = 64;
     g.ksplit = 64;
@@ -847,6 +861,7 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
                int act, hipStream_t s, int h2, const float* h2s, const LnArgs* ln = nullptr) {
   OppGemm g;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.prec = h2;
   g.h2_inv = (h2 == OPP_PREC_FP16X2 && h2s) ? h2s + 1 : nullptr;
   if (ln) {
@@ -898,8 +913,11 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
       OppGemm g;
     g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
       g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
       g.A0 = X;
       g.lda0 = C;
       g.ksplit = C;
@@ -1018,6 +1036,7 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   // C = 256: the 1/16 feature scaling is an exact power of two, so it commutes with the sum.
   OppGemm g;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.A0 = f3;
   g.lda0 = C;
   g.ksplit = C;
@@ -1207,6 +1226,7 @@ extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, i
   OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "linear: prec must be 0 (fp32), 1 (fp16x2) or 2 (bf16x3)");
   OppGemm g;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.prec = prec;
   g.h2_inv = (prec == OPP_PREC_FP16X2 && h2_scale) ? h2_scale + 1 : nullptr;
   g.A0 = A;
@@ -1231,6 +1251,7 @@ extern "C" int opp_linear_layernorm(const float* A, int M, int K, const float* W
   OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "linear_layernorm: prec must be 0, 1 or 2");
   OppGemm g;
   g.nonfinite = t_status_flag;
+  g.tile_policy = t_tile_policy;
   g.prec = prec;
   g.h2_inv = (prec == OPP_PREC_FP16X2 && h2_scale) ? h2_scale + 1 : nullptr;
   g.A0 = A;

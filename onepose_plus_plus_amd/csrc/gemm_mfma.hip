@@ -853,7 +853,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           for (int e = 0; e < nval; ++e) v[e] += rp[e];
         }
       } else if (g.res_mode == OPP_RES_BILINEAR2X) {
-        // bilinear x2 (align_corners=True) taps of the half-resolution residual (resnet.py:151,155)
+        // bilinear x2 (align_corners=True) taps of the half-resolution residual (resnet.py:151,155).
+        // No FMA contraction in this block: the compiler fuses differently in different tile instantiations, and
+        // every tile shape must produce the same bits (tools/tile_invariance_check.py).
+#pragma clang fp contract(off)
         const int ox = row % g.Wout;
         const int t = row / g.Wout;
         const int oy = t % g.Hout;
@@ -1136,6 +1139,14 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
         const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
         long long est = full * (nk * c.chunk * c.wpc + c.fixed);
         if (rem > 0) est += nk * c.chunk * ((rem + cus - 1) / cus) + c.fixed;
+        if (g.tile_policy == OPP_TILES_THROUGHPUT) {
+          // several forwards in flight (MatcherPool, bench --streams > 1): other streams' kernels fill the CUs a
+          // grid leaves idle, so what counts is the CU time a launch occupies, not its own latency: the larger tiles
+          // (64x64 per wave: fewer LDS bytes and barriers per MFMA) win even where they cover only part of the chip.
+          // Measured with 3 forwards in flight: +3.5 ... 6.5 % images/s, at -9 % for a single forward on its own.
+          if (tiles < 64 && c.cfg != 2) continue;
+          est = tiles * (nk * c.chunk + c.fixed / c.wpc);
+        }
         if (best < 0 || est < best) {
           best = est;
           cfg = c.cfg;

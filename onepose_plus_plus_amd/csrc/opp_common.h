@@ -52,6 +52,8 @@ enum { OPP_ACT_NONE = 0, OPP_ACT_RELU = 1, OPP_ACT_LEAKY = 2, OPP_ACT_QKV = 3 };
 //   FP16X2  x ~ hi + lo fp16 (22 significant bits, fp16 exponent range), 3 x v_mfma_f32_32x32x16_f16
 //   BF16X3  x = hi + mid + lo bf16 EXACTLY (24 bits, fp32 exponent range), 6 x v_mfma_f32_32x32x16_bf16
 enum { OPP_PREC_FP32 = 0, OPP_PREC_FP16X2 = 1, OPP_PREC_BF16X3 = 2 };
+// automatic tile choice: shortest launch (one forward at a time) or least CU time (several forwards in flight)
+enum { OPP_TILES_LATENCY = 0, OPP_TILES_THROUGHPUT = 1 };
 enum { OPP_RES_NONE = 0, OPP_RES_DIRECT = 1, OPP_RES_BILINEAR2X = 2 };
 
 struct OppGemm {
@@ -101,6 +103,7 @@ struct OppGemm {
   // beyond the fp16 range makes its lo half infinite); null = unchecked.  Unused by the other arithmetics.
   int* nonfinite = nullptr;
   unsigned long long* dbg_ts = nullptr;   // -DOPP_TUNING builds (ABL 9): 4 shader-clock stamps per wave
+  int tile_policy = OPP_TILES_LATENCY;   // OPP_TILES_*; only consulted when the launcher picks the tile itself
   int xcd_swizzle = 1;
   int vec_epilogue = 0;   // 16 B-per-lane epilogue allowed (alignment / divisibility checked by the launcher)
   // optional softmax statistics of the OUTPUT tile (score GEMM of the coarse matcher): per row

@@ -176,6 +176,7 @@ class OnePosePlus_model(nn.Module):
                 for p in self.backbone.parameters():
                     p.requires_grad = False
         self.gemm_precision = os.environ.get("OPP_GEMM_PRECISION", DEFAULT_GEMM_PRECISION)
+        self.tile_policy = "latency"
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -196,6 +197,18 @@ class OnePosePlus_model(nn.Module):
         if name != self.gemm_precision:
             self.__del__()
             self.gemm_precision = name
+            self._reset_runtime()
+        return self
+
+    def set_tile_policy(self, name):
+        """What the automatic GEMM / conv tile choice minimises (include/opp_hip.h `opp_config.tile_policy`):
+        "latency" (default: one forward at a time) or "throughput" (several forwards in flight on separate streams,
+        as `serving.MatcherPool` and `bench.py --streams > 1` run them).  Results are bit-identical either way."""
+        if name not in ("latency", "throughput"):
+            raise ValueError("tile_policy must be 'latency' or 'throughput'")
+        if name != getattr(self, "tile_policy", "latency"):
+            self.__del__()
+            self.tile_policy = name
             self._reset_runtime()
         return self
 
@@ -274,6 +287,7 @@ class OnePosePlus_model(nn.Module):
         if self.gemm_precision not in GEMM_PRECISIONS:
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
         c.gemm_precision = GEMM_PRECISIONS[self.gemm_precision]
+        c.tile_policy = 1 if getattr(self, "tile_policy", "latency") == "throughput" else 0
         return c
 
     def _ensure_ready(self, device):

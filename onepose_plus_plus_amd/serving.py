@@ -25,6 +25,8 @@ class MatcherPool:
             m = OnePosePlus_model(config).eval()
             if gemm_precision is not None:
                 m.set_gemm_precision(gemm_precision)
+            if int(n_streams) > 1:
+                m.set_tile_policy("throughput")      # several forwards share the chip: tiles chosen for least CU time
             m.load_state_dict(state_dict, strict=True)
             self.models.append(m.to(self.device))
             self.streams.append(torch.cuda.Stream(device=self.device))

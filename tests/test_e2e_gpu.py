@@ -296,6 +296,18 @@ def test_matcher_pool_matches_sequential():
             assert torch.equal(r[k], g[k]), k
 
 
+def test_tile_policy_does_not_change_results():
+    """`set_tile_policy("throughput")` (MatcherPool, bench --streams > 1) picks other tile shapes: bit-identical outputs."""
+    from tests import hip_ops as ops
+    cfg, sd, data = H.e2e_setup("e2e_512x512_n2000_thr0")
+    a = ops.run_model(ops.make_model(cfg, sd), data)
+    m = ops.make_model(cfg, sd)
+    m.set_tile_policy("throughput")
+    b = ops.run_model(m.cuda(), data)
+    for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_precisions_agree_at_full_size():
     """512x512 x 5k points, thr 0: the fp16x2-split GEMMs select exactly the matches of the fp32 GEMMs and
     agree on confidences / fine offsets far inside the 1e-4 bar."""
