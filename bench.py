@@ -107,6 +107,8 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the other-arithmetic and fine-stage legs")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "fp16x2", "fp16x2_all"],
                     help="GEMM arithmetic (default: the module default bf16x3 / OPP_GEMM_PRECISION)")
+    ap.add_argument("--tile-policy", default="latency", choices=["latency", "throughput"],
+                    help="automatic GEMM / conv tile choice for the headline (see opp_config.tile_policy)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "3")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
                          "2 Ray workers per GPU, inference_OnePosePlus.py:18-26)")
@@ -161,7 +163,10 @@ def run(args):
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
-    policy = "throughput" if n_streams > 1 else "latency"     # tile choice for several forwards in flight (opp_config.tile_policy)
+    # tile choice (opp_config.tile_policy): the headline and its roofline use the per-launch-latency tiles, whose kernels
+    # fill the chip on their own, so a symbol's stand-alone duration is a meaningful roofline figure; the least-CU-time
+    # tiles that serving.MatcherPool uses with several forwards in flight are reported as `config.throughput_tiles_leg`
+    policy = args.tile_policy
     model.set_tile_policy(policy)
     models = [model]
     for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
@@ -388,6 +393,22 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
     for m in models:
         m.set_gemm_precision(precision).to(dev)
     legs["other_arithmetics"] = other
+    if n_streams > 1 and args.tile_policy == "latency":
+        # the same workload with the tiles chosen for least CU time (what MatcherPool runs with several forwards in flight)
+        for m in models:
+            m.set_tile_policy("throughput").to(dev)
+        for k in range(n_streams):
+            step(0, k)
+        torch.cuda.synchronize(dev)
+        run_steps(2 * n_streams)
+        n = min(args.steps, 40)
+        t1 = time.perf_counter()
+        run_steps(n)
+        torch.cuda.synchronize(dev)
+        legs["throughput_tiles_leg"] = {"value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
+                                        "note": "opp_config.tile_policy = 1: bit-identical results, fewer / larger tiles per launch"}
+        for m in models:
+            m.set_tile_policy("latency").to(dev)
     try:
         legs["fine_leg"] = fine_leg(torch, dev, precision, lib, _lib)
     except Exception as e:      # the fixture is optional for the headline
