@@ -420,9 +420,15 @@ class OnePosePlus_model(nn.Module):
             raise NotImplementedError("HIP path supports query_image of shape [B,1,H,W] (got %s)" % (tuple(img.shape),))
         if self.training:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                raise RuntimeError("onepose_plus_plus_amd.OnePosePlus_model: the train()-mode FORWARD runs on the HIP path "
-                                   "(BatchNorm batch statistics, training branch of get_coarse_match), but there is no "
-                                   "backward yet -- call it under torch.no_grad() (SURVEY.md §8f-3)")
+                # training step (lightning_model:54-81): forward on the HIP path; `conf_matrix` / `expec_f` carry a
+                # grad_fn whose backward re-evaluates the graph with PyTorch ops (train_autograd.TrainForward)
+                from .train_autograd import TrainForward
+                names, params = zip(*self.named_parameters())
+                conf, expec = TrainForward.apply(self, data, names, *params)
+                data["conf_matrix"] = conf
+                if self.config["fine_matching"]["enable"] and "expec_f" in data:
+                    data["expec_f"] = expec
+                return
             return self._forward_train(data)
         if img.size(0) > 1 or "query_image_mask" in data:
             return self._forward_batch(data)

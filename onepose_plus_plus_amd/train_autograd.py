@@ -1,0 +1,194 @@
+"""Backward of the train()-mode forward.
+
+`PL_OnePosePlus.training_step` (src/lightning_model/OnePosePlus_lightning_model.py:54-81) runs `self.matcher(batch)`,
+then `fine_supervision` and the loss (`losses.py:114-142`), which differentiates two outputs of the matcher:
+`conf_matrix` (focal loss over all B x N x L entries) and `expec_f` (fine L2 loss).  The FORWARD of that step runs on
+the hand-written HIP path (`OnePosePlus_model._forward_train`: BatchNorm batch statistics, training branch of
+get_coarse_match, running-statistics update) and is what every returned value comes from.  The BACKWARD is not
+hand-written yet: `TrainForward` is a `torch.autograd.Function` whose `backward` re-evaluates the same graph with
+PyTorch ops on the same device from the saved inputs -- match indices frozen to the ones the HIP forward selected,
+BatchNorm again with batch statistics but WITHOUT touching the running statistics -- and lets `torch.autograd` produce
+the parameter gradients.  This file is that differentiable restatement (functional, flat parameter dict); it is used
+for gradients only, never for forward values, and is independent of the test-side oracle.
+
+Each function cites the reference code it differentiates (paths relative to src/models/OnePosePlus/).
+"""
+import torch
+import torch.nn.functional as F
+
+_EPS_BN = 1e-5
+_EPS_LN = 1e-5
+
+
+def _bn(p, name, x):
+    # nn.BatchNorm2d in train(): batch statistics (backbone/resnet.py:25-26); running statistics were already updated
+    # by the HIP forward, so none are passed here
+    return F.batch_norm(x, None, None, p[name + ".weight"], p[name + ".bias"], True, 0.0, _EPS_BN)
+
+
+def _block(p, name, x, stride, bn):          # BasicBlock.forward, backbone/resnet.py:37-45
+    y = F.relu(bn(p, name + ".bn1", F.conv2d(x, p[name + ".conv1.weight"], None, stride, 1)))
+    y = bn(p, name + ".bn2", F.conv2d(y, p[name + ".conv2.weight"], None, 1, 1))
+    if stride != 1:
+        x = bn(p, name + ".downsample.1", F.conv2d(x, p[name + ".downsample.0.weight"], None, stride, 0))
+    return F.relu(x + y)
+
+
+def _backbone(p, img, bn_eval_stats=None):
+    """ResNetFPN_8_2.forward, backbone/resnet.py:141-164.  bn_eval_stats: name -> (running_mean, running_var) for a
+    frozen pretrained backbone, which the reference keeps in eval mode (OnePosePlusModel.py:109-113)."""
+    bn = _bn if bn_eval_stats is None else (
+        lambda pp, n, x: F.batch_norm(x, bn_eval_stats[n][0], bn_eval_stats[n][1], pp[n + ".weight"], pp[n + ".bias"], False, 0.0, _EPS_BN))
+    b = "backbone."
+    x0 = F.relu(bn(p, b + "bn1", F.conv2d(img, p[b + "conv1.weight"], None, 2, 3)))
+    x1 = _block(p, b + "layer1.1", _block(p, b + "layer1.0", x0, 1, bn), 1, bn)
+    x2 = _block(p, b + "layer2.1", _block(p, b + "layer2.0", x1, 2, bn), 1, bn)
+    x3 = _block(p, b + "layer3.1", _block(p, b + "layer3.0", x2, 2, bn), 1, bn)
+    x3_out = F.conv2d(x3, p[b + "layer3_outconv.weight"])
+    t = F.conv2d(x2, p[b + "layer2_outconv.weight"]) + F.interpolate(x3_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+    t = F.leaky_relu(bn(p, b + "layer2_outconv2.1", F.conv2d(t, p[b + "layer2_outconv2.0.weight"], None, 1, 1)), 0.01)
+    x2_out = F.conv2d(t, p[b + "layer2_outconv2.3.weight"], None, 1, 1)
+    t = F.conv2d(x1, p[b + "layer1_outconv.weight"]) + F.interpolate(x2_out, scale_factor=2.0, mode="bilinear", align_corners=True)
+    t = F.leaky_relu(bn(p, b + "layer1_outconv2.1", F.conv2d(t, p[b + "layer1_outconv2.0.weight"], None, 1, 1)), 0.01)
+    return x3_out, F.conv2d(t, p[b + "layer1_outconv2.3.weight"], None, 1, 1)
+
+
+def _kpt_encoding(p, kpts, desc):
+    """normalize_3d_keypoints + KeypointEncoding_linear (utils/normalize.py:16-26, utils/position_encoding.py:54-79;
+    per-point channel norm = quirk q3, batch-0 extent = quirk q4)."""
+    extent = kpts[0].max(dim=0).values - kpts[0].min(dim=0).values
+    x = (kpts - kpts.mean(dim=-2, keepdim=True)) / (extent.max() * 0.6)
+    pre = "kpt_3d_pos_encoding.encoder."
+    idxs = sorted({int(k[len(pre):].split(".")[0]) for k in p if k.startswith(pre)})
+    for n, i in enumerate(idxs):
+        x = F.linear(x, p[pre + "%d.weight" % i], p[pre + "%d.bias" % i])
+        if n < len(idxs) - 1:
+            mu = x.mean(dim=-1, keepdim=True)
+            var = x.var(dim=-1, unbiased=False, keepdim=True)
+            x = F.relu((x - mu) / torch.sqrt(var + _EPS_LN))
+    return desc + x.transpose(2, 1)
+
+
+def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loftr_module/linear_attention.py:29-61
+    Q, K = F.elu(q) + 1, F.elu(k) + 1
+    if q_mask is not None:
+        Q = Q * q_mask[:, :, None, None]
+    if kv_mask is not None:
+        K = K * kv_mask[:, :, None, None]
+        v = v * kv_mask[:, :, None, None]
+    S = v.size(1)
+    v = v / S
+    KV = torch.einsum("nshd,nshv->nhdv", K, v)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(dim=1)) + eps)
+    return torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S
+
+
+def _encoder_layer(p, name, nhead, x, source, x_mask=None, source_mask=None):      # loftr_module/transformer.py:65-94
+    B, _, C = x.shape
+    D = C // nhead
+    q = F.linear(x, p[name + ".q_proj.weight"]).view(B, -1, nhead, D)
+    k = F.linear(source, p[name + ".k_proj.weight"]).view(B, -1, nhead, D)
+    v = F.linear(source, p[name + ".v_proj.weight"]).view(B, -1, nhead, D)
+    msg = _linear_attention(q, k, v, x_mask, source_mask).reshape(B, -1, C)
+    msg = F.layer_norm(F.linear(msg, p[name + ".merge.weight"]), (C,), p[name + ".norm1.weight"], p[name + ".norm1.bias"], _EPS_LN)
+    msg = F.linear(F.relu(F.linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"])), p[name + ".mlp.2.weight"])
+    return x + F.layer_norm(msg, (C,), p[name + ".norm2.weight"], p[name + ".norm2.bias"], _EPS_LN)
+
+
+def _transformer(p, name, tcfg, f3, f2, mask=None):      # loftr_module/transformer.py:133-171 (f3 already [B, N, C])
+    for i, kind in enumerate(list(tcfg["layer_names"]) * tcfg["layer_iter_n"]):
+        n = "%s.layers.%d" % (name, i)
+        if kind == "self":
+            f2, f3 = _encoder_layer(p, n, tcfg["nhead"], f2, f2, mask, mask), _encoder_layer(p, n, tcfg["nhead"], f3, f3)
+        else:       # cross: both streams from the pre-update tensors (quirk q6)
+            f2, f3 = (_encoder_layer(p, n, tcfg["nhead"], f2, f3, x_mask=mask),
+                      _encoder_layer(p, n, tcfg["nhead"], f3, f2, source_mask=mask))
+    return f3, f2
+
+
+def differentiable_forward(p, cfg, inputs, matches, pe, bn_eval_stats=None):
+    """-> (conf_matrix [B,N,L], expec_f [M',3] or None) as differentiable functions of the parameter dict `p`.
+    `inputs`: query_image, keypoints3d, descriptors3d_db, descriptors3d_coarse_db (or None), query_image_mask [B,L] or
+    None.  `matches` = (b_ids, i_ids, j_ids) chosen by the HIP forward (constants).  OnePosePlusModel.py:96-201."""
+    img = inputs["query_image"]
+    feat_c, feat_f = _backbone(p, img, bn_eval_stats)
+    if pe is not None:                                        # PositionEncodingSine.forward (position_encoding.py:37-42)
+        feat_c = feat_c + pe[:, :, :feat_c.size(2), :feat_c.size(3)]
+    tokens2d = feat_c.flatten(2).transpose(1, 2)
+    bank_c = inputs["descriptors3d_coarse_db"] if inputs.get("descriptors3d_coarse_db") is not None else inputs["descriptors3d_db"]
+    if cfg["keypoints_encoding"]["enable"]:
+        bank_c = _kpt_encoding(p, inputs["keypoints3d"], bank_c)
+    mask = inputs.get("query_image_mask")
+    f3, f2 = _transformer(p, "loftr_coarse", cfg["loftr_coarse"], bank_c.transpose(1, 2), tokens2d, mask)
+    C = f3.shape[-1]
+    sim = torch.einsum("nlc,nsc->nls", f3 / C ** 0.5, f2 / C ** 0.5) / (cfg["coarse_matching"]["dual_softmax"]["temperature"] + 1e-4)
+    if mask is not None:                                      # coarse_matching.py:108-114
+        sim = sim + torch.where(mask[:, None].bool(), 0.0, -1e9).to(sim.dtype)
+    conf = F.softmax(sim, 1) * F.softmax(sim, 2)              # coarse_matching.py:115
+    if not cfg["fine_matching"]["enable"]:
+        return conf, None
+    b_ids, i_ids, j_ids = matches
+    if b_ids.numel() == 0:
+        return conf, None
+    fcfg = cfg["loftr_fine"]
+    W, Cf = fcfg["window_size"], fcfg["d_model"]
+    stride = feat_f.shape[2] // feat_c.shape[2]
+    win = F.unfold(feat_f, kernel_size=(W, W), stride=stride, padding=W // 2)       # fine_preprocess.py:41-55
+    win = win.view(feat_f.shape[0], Cf, W * W, -1).permute(0, 3, 2, 1)[b_ids, j_ids]
+    g3 = inputs["descriptors3d_db"].permute(0, 2, 1)[b_ids, i_ids].unsqueeze(1)      # [M', 1, C]: the RAW fine bank (quirk q8)
+    if fcfg["enable"]:
+        g3, win = _transformer(p, "loftr_fine", fcfg, g3, win)
+    f0 = g3[:, g3.shape[1] // 2, :]                                                  # fine_matching.py:63-68
+    heat = torch.softmax(torch.einsum("mc,mrc->mr", f0, win) / Cf ** 0.5, dim=1)
+    lin = (torch.linspace(0, W - 1, W, device=heat.device) / (W - 1) - 0.5) * 2
+    gx, gy = lin.view(1, W).expand(W, W).reshape(-1), lin.view(W, 1).expand(W, W).reshape(-1)
+    coords = torch.stack([(gx * heat).sum(-1), (gy * heat).sum(-1)], dim=-1)
+    grid = torch.stack([gx, gy], dim=-1)
+    var = torch.sum(grid[None] ** 2 * heat[:, :, None], dim=1) - coords ** 2
+    std = torch.sum(torch.sqrt(torch.clamp(var, min=1e-10)), -1)                      # fine_matching.py:92-94
+    return conf, torch.cat([coords, std[:, None]], -1)
+
+
+class TrainForward(torch.autograd.Function):
+    """forward: the HIP train()-mode forward of `model` (fills `data` like the reference); returns the two outputs the
+    loss differentiates.  backward: gradients of those outputs w.r.t. the parameters by torch.autograd on
+    `differentiable_forward` (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, model, data, names, *params):
+        with torch.no_grad():
+            model._forward_train(data)
+        ctx.model, ctx.names = model, names
+        cfg = model.config
+        ctx.inputs = {k: data[k] for k in ("query_image", "keypoints3d", "descriptors3d_db") if k in data}
+        ctx.inputs["descriptors3d_coarse_db"] = data.get("descriptors3d_coarse_db")
+        ctx.inputs["query_image_mask"] = data["query_image_mask"].flatten(-2).float() if "query_image_mask" in data else None
+        ctx.matches = (data["b_ids"], data["i_ids"], data["j_ids"])
+        ctx.has_fine = bool(cfg["fine_matching"]["enable"]) and "expec_f" in data
+        ctx.save_for_backward(*params)
+        expec = data["expec_f"] if ctx.has_fine else data["conf_matrix"].new_zeros(0, 3)
+        return data["conf_matrix"], expec
+
+    @staticmethod
+    def backward(ctx, g_conf, g_expec):
+        model = ctx.model
+        params = ctx.saved_tensors
+        need = [ctx.needs_input_grad[3 + i] for i in range(len(params))]
+        with torch.enable_grad():
+            leaves = [p.detach().requires_grad_(n) for p, n in zip(params, need)]
+            p = dict(zip(ctx.names, leaves))
+            pe = model.dense_pos_encoding.pe.to(leaves[0].device) if model.dense_pos_encoding is not None else None
+            frozen = bool(model.loftr_backbone_pretrained) and bool(model.config["loftr_backbone"]["pretrained_fix"])
+            stats = None
+            if frozen:       # OnePosePlusModel.py:109-113: the frozen backbone runs in eval mode
+                stats = {n[:-len(".running_mean")]: (b, dict(model.named_buffers())[n[:-len(".running_mean")] + ".running_var"])
+                         for n, b in model.named_buffers() if n.endswith(".running_mean")}
+            conf, expec = differentiable_forward(p, model.config, ctx.inputs, ctx.matches, pe, stats)
+            outs, gouts = [conf], [g_conf]
+            if ctx.has_fine and expec is not None and g_expec is not None:
+                outs.append(expec)
+                gouts.append(g_expec)
+            wanted = [l for l, n in zip(leaves, need) if n]
+            grads = torch.autograd.grad(outs, wanted, gouts, allow_unused=True) if wanted else ()
+        it = iter(grads)
+        return (None, None, None) + tuple(next(it) if n else None for n in need)

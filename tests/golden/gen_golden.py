@@ -194,6 +194,27 @@ def gen_train():
         for i, d in enumerate(draws):
             out["randint_%d" % i] = d.numpy()
         out["n_randint"] = np.array(len(draws))
+        # gradients of a fixed scalar of the two outputs the loss differentiates (losses.py:125-133), by the
+        # reference's own autograd: digest (sum, L2 norm) for every parameter + a few whole tensors
+        from tests.helpers import train_loss_weights, GRAD_TENSORS
+        d2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in train_setup(name)[2].items()}
+        model2 = cls(cfg)
+        model2.load_state_dict(sd, strict=True)
+        model2.train()
+        replay = [d.clone() for d in draws]
+        torch.randint = lambda *a, **kw: replay.pop(0)
+        try:
+            model2(d2)
+        finally:
+            torch.randint = real
+        wc, we = train_loss_weights(d2["conf_matrix"].shape, d2["expec_f"].shape)
+        ((d2["conf_matrix"] * wc).sum() + (d2["expec_f"] * we).sum()).backward()
+        gnames = [n for n, p_ in model2.named_parameters() if p_.grad is not None]
+        out["grad_names"] = np.array(gnames)
+        out["grad_digest"] = np.array([[float(model2.get_parameter(n).grad.double().sum()),
+                                        float(model2.get_parameter(n).grad.double().norm())] for n in gnames])
+        for n in GRAD_TENSORS:
+            out["grad/" + n] = model2.get_parameter(n).grad.numpy()
         after = model.state_dict()
         for k, v in after.items():          # running statistics after ONE training forward
             if k.endswith(("running_mean", "running_var", "num_batches_tracked")):

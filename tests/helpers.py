@@ -72,6 +72,32 @@ def train_setup(name):
     return cfg, sd, data
 
 
+GRAD_TENSORS = ("backbone.conv1.weight", "backbone.bn1.weight", "backbone.layer3.1.bn2.bias", "backbone.layer1_outconv.weight",
+                "kpt_3d_pos_encoding.encoder.9.weight", "loftr_coarse.layers.0.q_proj.weight", "loftr_coarse.layers.5.norm2.weight",
+                "loftr_fine.layers.1.mlp.2.weight")
+
+
+def train_loss_weights(conf_shape, expec_shape):
+    """fixed scalar L = sum(conf_matrix * wc) + sum(expec_f * we) whose parameter gradients the train fixtures store"""
+    g = torch.Generator().manual_seed(5)
+    return torch.rand(tuple(conf_shape), generator=g), torch.randn(tuple(expec_shape), generator=g)
+
+
+def assert_train_grads(named_grads, gold, rel=2e-3, where=""):
+    """named_grads: name -> gradient tensor of the same scalar; digest of every parameter + the stored tensors"""
+    names = [str(n) for n in gold["grad_names"]]
+    dig = gold["grad_digest"]
+    assert len(names) > 100
+    for n, (gs, gn) in zip(names, dig):
+        g = named_grads[n].double().cpu()
+        assert abs(float(g.norm()) - gn) <= rel * max(gn, 1e-12) + 1e-9, (where, n, float(g.norm()), gn)
+        assert abs(float(g.sum()) - gs) <= rel * gn * (g.numel() ** 0.5) + 1e-9, (where, n, float(g.sum()), gs)
+    for n in GRAD_TENSORS:
+        g, v = to_np(named_grads[n]), gold["grad/" + n]
+        err = np.abs(g - v).max()
+        assert err <= rel * np.abs(v).max() + 1e-12, (where, n, float(err), float(np.abs(v).max()))
+
+
 class RecordedRandint:
     """stands in for torch.randint in the training branch of get_coarse_match: replays the draws recorded when the
     reference produced the fixture (the draws themselves are device / generator specific, coarse_matching.py:192-204)"""
@@ -194,7 +220,7 @@ def conf_digest_t(conf):
 
 def assert_batched_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_px=TOL_PIXEL, where=""):
     """B > 1: same checks as assert_match_outputs with a [B,N,L] confidence matrix"""
-    conf = got["conf_matrix"].float().cpu()
+    conf = got["conf_matrix"].detach().float().cpu()
     dig = {"conf_rowsum": conf.sum(2).numpy(), "conf_colsum": conf.sum(1).numpy(),
            "conf_rowmax": conf.max(2).values.numpy(), "conf_colmax": conf.max(1).values.numpy(), "conf_matrix": conf.numpy()}
     for k, v in dig.items():
@@ -210,7 +236,7 @@ def assert_batched_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol
 def assert_train_outputs(got, state, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_px=TOL_PIXEL, tol_bn=1e-4, where=""):
     """train()-mode forward: matches / confidences / fine offsets like the batched case (M' padded rows, M predicted
     ones) + the BatchNorm running statistics after the forward (`state`: name -> tensor)."""
-    assert_batched_outputs(got, {k: v for k, v in gold.items() if not k.startswith(("bn/", "randint_", "n_randint"))},
+    assert_batched_outputs(got, {k: v for k, v in gold.items() if not k.startswith(("bn/", "randint_", "n_randint", "grad"))},
                            tol_conf, tol_off, tol_px, where)
     assert len(gold["b_ids"]) > len(gold["mconf"]) > 0          # ground-truth padding present
     n = 0
