@@ -360,6 +360,33 @@ def test_matcher_pool_matches_sequential():
             assert torch.equal(r[k], g[k]), k
 
 
+def test_matcher_pool_waits_for_the_producer_stream():
+    """Inputs produced ASYNCHRONOUSLY on the caller's stream (what ingest.read_grayscale_u8 does: upload + resize
+    kernels) must be complete before a pool worker's stream reads them: the image buffer is overwritten behind a long
+    queue of work on the current stream, then `map` is called at once."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.serving import MatcherPool
+    from onepose_plus_plus_amd.synthetic import make_inputs
+    cfg, sd, _ = H.e2e_setup("e2e_128x128_n300_thr0")
+    datas = [make_inputs(300, (128, 128), 70 + i) for i in range(4)]
+    ref = [ops.run_model(ops.make_model(cfg, sd), d) for d in datas]
+    pool = MatcherPool(cfg, sd, n_streams=2)
+    dev = [{k: v.cuda() for k, v in d.items()} for d in datas]
+    real = [d["query_image"].clone() for d in dev]
+    for d in dev:
+        d["query_image"].zero_()                     # stale content
+    torch.cuda.synchronize()
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(20):                              # ~tens of ms of queued work on the current stream ...
+        busy = busy @ busy * 1e-3
+    for d, r in zip(dev, real):
+        d["query_image"].copy_(r)                    # ... behind which the real images are written
+    got = pool.map(dev)
+    torch.cuda.synchronize()
+    for r, g in zip(ref, got):
+        assert torch.equal(r["conf_matrix"], g["conf_matrix"]) and torch.equal(r["i_ids"], g["i_ids"])
+
+
 def test_tile_policy_does_not_change_results():
     """`set_tile_policy("throughput")` (MatcherPool, bench --streams > 1) picks other tile shapes: bit-identical outputs."""
     from tests import hip_ops as ops
