@@ -225,6 +225,13 @@ int opp_layer_norm(const float* x, const float* gamma, const float* beta, const 
 int opp_image_ingest_u8(const unsigned char* src, int h, int w, int src_stride, int h_new, int w_new,
                         float* dst, int dst_stride, unsigned char* dst_u8, void* stream);
 
+/* ---- per-object descriptor bank (the step before the path) ----------------------
+ * mean_descriptors_and_scores (src/sfm_utils/postprocess/feature_process.py:527-541): out[i][:] = mean over rows
+ * [offsets[i], offsets[i+1]) of `rows` [R][D] fp32 (the 2D features of the track of 3D point i, concatenated in
+ * track order by gather_3d_ann, :255-311); float32 row-by-row accumulation and float32 division like numpy's
+ * axis-0 mean, i.e. bit-identical to the reference.  offsets: n_seg + 1 int64 on the device. */
+int opp_segmented_mean(const float* rows, int D, const long long* offsets, int n_seg, float* out, void* stream);
+
 /* ---- pose from the matches (next row after the matcher) --------------------
  * PnP-RANSAC on the device: replaces ransac_PnP / cv2.solvePnPRansac(EPNP, 10000 iterations)
  * (src/utils/metric_utils.py:121-204) so the matches never leave the GPU.  pts2d [n][2] (pixels),

@@ -87,6 +87,7 @@ SIGNATURES = {
     "opp_pack_b3": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_layer_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "opp_image_ingest_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "opp_segmented_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "opp_debug_timestamps": (c_int, [c_void_p]),
     "opp_pnp_workspace_bytes": (c_size_t, [c_int]),
     "opp_pnp_ransac": (c_int, [c_void_p, c_void_p, c_int, POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double,

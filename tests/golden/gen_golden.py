@@ -223,6 +223,45 @@ def gen_train():
         print(name, "M' =", len(data["b_ids"]), "M =", len(data["mconf"]), "draws", [tuple(d.shape) for d in draws])
 
 
+def gen_bankbuild():
+    """The reference's own gather_3d_ann + mean_descriptors_and_scores (feature_process.py:255-311, :527-541) on
+    synthetic tracks; the module's imports of packages that are not installed here are stubbed."""
+    import types
+    from tests.helpers import bankbuild_inputs, BANKBUILD_CASES
+    for name in ("h5py", "ray", "ray.actor", "loguru", "tqdm"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+    sys.modules["ray"].remote = lambda *a, **k: (lambda f: f)
+    sys.modules["ray.actor"].ActorHandle = object
+    sys.modules["loguru"].logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, error=lambda *a, **k: None)
+    sys.modules["tqdm"].tqdm = lambda x, *a, **k: x
+    # load the file itself (its packages' __init__ pull in cv2 / COLMAP tooling that this step does not use)
+    import importlib.util
+    saved = {k: sys.modules.get(k) for k in ("src", "src.utils", "src.utils.colmap", "src.utils.ray_utils")}
+    for k in saved:
+        sys.modules[k] = types.ModuleType(k)
+    sys.modules["src.utils.colmap"].read_write_model = None
+    for fn in ("ProgressBar", "chunks", "chunk_index", "split_dict"):
+        setattr(sys.modules["src.utils.ray_utils"], fn, None)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_feature_process", "/root/reference/src/sfm_utils/postprocess/feature_process.py")
+        FP = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(FP)
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+    for name, (n, dim, seed) in BANKBUILD_CASES.items():
+        feat, score, xyzs, points_idxs = bankbuild_inputs(n, dim, seed)
+        pos, desc, scores, idxs = FP.gather_3d_ann(feat, score, xyzs, points_idxs, verbose=False)
+        avg, avg_scores, idxs2 = FP.mean_descriptors_and_scores(desc, scores, idxs)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), kp3d_position=pos, idxs=idxs, avg_descriptors=avg,
+                            avg_scores=avg_scores, desc_rowsum=desc.sum(1), n_rows=np.array(desc.shape[0]))
+        print(name, "points", len(idxs), "rows", desc.shape[0], avg.dtype)
+
+
 def gen_e2e():
     cls = load_reference_model_class()
     for name, (hw, n, thr, wseed, iseed, fine) in E2E_CASES.items():
@@ -317,7 +356,7 @@ if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     steps = {"stages": gen_stage_features, "matcher": gen_matcher, "fine": gen_fine, "e2e": gen_e2e,
              "transformer": gen_transformer, "highconf": gen_highconf, "batch": gen_batch,
-             "train": gen_train}
+             "train": gen_train, "bankbuild": gen_bankbuild}
     for k, fn in steps.items():
         if not only or k in only:
             fn()

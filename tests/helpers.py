@@ -111,6 +111,26 @@ class RecordedRandint:
         return d.to(device) if device is not None else d
 
 
+def bankbuild_inputs(n_points, dim, seed):
+    """Synthetic SfM tracks for the bank builder: every filtered 3D point merges 1-3 COLMAP points, each observed in
+    1-12 images -> (kp3d_id_feature {old id: [n_obs, dim] float32}, kp3d_id_score, xyzs [n_points, 3], points_idxs)."""
+    rng = np.random.default_rng(seed)
+    feat, score, points_idxs, nxt = {}, {}, {}, 7
+    for i in range(n_points):
+        olds = []
+        for _ in range(int(rng.integers(1, 4))):
+            n_obs = int(rng.integers(1, 13))
+            feat[nxt] = (rng.standard_normal((n_obs, dim)) * np.exp(rng.uniform(-3, 3))).astype(np.float32)
+            score[nxt] = rng.random(n_obs).astype(np.float32)
+            olds.append(nxt)
+            nxt += int(rng.integers(1, 5))
+        points_idxs[i] = olds
+    return feat, score, rng.standard_normal((n_points, 3)), points_idxs
+
+
+BANKBUILD_CASES = {"bankbuild_n500_d128": (500, 128, 21), "bankbuild_n300_d256": (300, 256, 22)}
+
+
 def highconf_geometry(name):
     """The synthetic object of a high-confidence case: a pinhole camera K, a ground-truth object pose [R | t] and
     3D keypoints such that planted point i projects exactly onto the coarse-grid coordinate (8 jx, 8 jy) of its
