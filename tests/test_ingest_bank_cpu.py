@@ -1,5 +1,6 @@
 """CPU: the ingest oracle (restated cv2.resize 8-bit INTER_LINEAR + /255; parity unpinned, see its header),
 the host-side resize rule, and the object-bank reader for the reference's .npz format."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -76,3 +77,56 @@ def test_object_bank_npz_round_trip(tmp_path):
 def test_ingest_refuses_cpu():
     with pytest.raises((RuntimeError, OSError)):
         PI.read_grayscale_u8(np.zeros((8, 8), dtype=np.uint8), device="cpu")
+
+
+def _load_reference_dataset_class():
+    """The reference's own dataset file (src/datasets/OnePosePlus_inference_dataset.py) and its data_utils, loaded by
+    path with stubs for the packages that are not installed here (cv2, loguru) -- neither is used by read_anno3d."""
+    import importlib.util
+    import sys
+    import types
+    saved = {k: sys.modules.get(k) for k in ("cv2", "loguru", "src", "src.utils", "src.utils.data_io", "src.utils.data_utils")}
+    try:
+        for k in ("cv2", "src", "src.utils", "src.utils.data_io"):
+            sys.modules[k] = types.ModuleType(k)
+        lg = types.ModuleType("loguru")
+        lg.logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None)
+        sys.modules["loguru"] = lg
+        sys.modules["src.utils.data_io"].read_grayscale = None
+        spec = importlib.util.spec_from_file_location("src.utils.data_utils", "/root/reference/src/utils/data_utils.py")
+        du = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(du)
+        sys.modules["src.utils.data_utils"] = du
+        sys.modules["src.utils"].data_utils = du
+        spec = importlib.util.spec_from_file_location("ref_inference_dataset", "/root/reference/src/datasets/OnePosePlus_inference_dataset.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.OnePosePlusInferenceDataset
+    finally:
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="/root/reference not mounted")
+@pytest.mark.parametrize("n,shape3d", [(300, 7000), (900, 500)])
+def test_object_bank_matches_reference_read_anno3d(tmp_path, n, shape3d):
+    """`ObjectBank.from_npz` against the reference's own `OnePosePlusInferenceDataset.read_anno3d`
+    (src/datasets/OnePosePlus_inference_dataset.py:109-160) on the same files: identical tensors, including the
+    with-replacement sub-sampling above `shape3d` (same torch RNG state -> same draw)."""
+    import types
+    cls = _load_reference_dataset_class()
+    rng = np.random.default_rng(n)
+    path = str(tmp_path / "anno_3d_average.npz")
+    ObjectBank.save_npz(path, rng.standard_normal((n, 3)), rng.standard_normal((128, n)).astype(np.float32),
+                        np.ones((n, 1)), rng.standard_normal((256, n)).astype(np.float32))
+    stub = types.SimpleNamespace(shape3d=shape3d)
+    torch.manual_seed(77)
+    kp, df, dc, sc, n_orig = cls.read_anno3d(stub, path, pad=True, load_3d_coarse=True)
+    torch.manual_seed(77)
+    bank = ObjectBank.from_npz(path, shape3d=shape3d, device="cpu")
+    assert bank.num_3d_orig == n_orig == n
+    assert torch.equal(bank.keypoints3d[0], kp) and torch.equal(bank.descriptors3d_db[0], df)
+    assert torch.equal(bank.descriptors3d_coarse_db[0], dc) and torch.equal(bank.scores3d, sc)
+    assert kp.shape[0] == min(n, shape3d)
