@@ -183,19 +183,22 @@ int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* ban
              float* expec_f, float* mkpts_f, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
-/* NHWC convolution as implicit GEMM on the fp32 MFMA.  x [Hin][Win][cin_pad]; w_packed
- * [cout_pad][ks*ks*cin_pad] (from opp_pack_conv_weight); bias [cout_pad] or NULL; residual:
+/* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
+ * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:
+ * ks*ks*cin_pad, or the shorter K-tail packing for a 3x3 kernel over 32 n + (1..4) channels); bias [cout_pad] or NULL; residual:
  * res_mode 0 none, 1 same-shape NHWC [Hout][Wout][cout_pad], 2 bilinear x2 (align_corners)
  * upsample of NHWC [Hout/2][Wout/2][cout_pad]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
  * tile_cfg < 0 selects automatically.  prec = operand arithmetic: 0 fp32; 1 fp16x2 (w_packed additionally
  * pre-split by opp_pack_h2, h2_scale = the scale2 pointer given to it, or NULL); 2 bf16x3 (w_packed pre-split by
  * opp_pack_b3, 1.5x the floats). */
-int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed,
+int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin, const float* w_packed,
                     const float* bias, int cout_pad, int ks, int stride, const float* residual,
                     int res_mode, int act, float* y, int tile_cfg, int prec, const float* h2_scale,
                     void* stream);
 int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks,
                          int cout_pad, int cin_pad, float* out, void* stream);
+/* floats per packed weight row of a (cin, ks) convolution */
+int opp_conv_packed_k(int cin, int ks);
 /* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  prec as above (1: W pre-split by opp_pack_h2,
  * 2: by opp_pack_b3). */
 int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,

@@ -79,6 +79,7 @@ SIGNATURES = {
                          c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "opp_conv_packed_k": (c_int, [c_int, c_int]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -49,7 +49,7 @@ struct ConvDesc {  // one packed convolution
   int w_idx = -1;   // weight index in the state-dict table
   int bn_idx = -1;  // index of <bn>.weight (bias, running_mean, running_var follow) or -1
   int cin = 0, cout = 0, ks = 1;
-  float* w = nullptr;     // packed [cout_pad][ks*ks*cin_pad]
+  float* w = nullptr;     // packed [cout_pad][k_len()]
   float* bias = nullptr;  // [cout_pad] (folded BN shift) or nullptr
   float* h2s = nullptr;   // fp16x2 only: {scale, 1/scale} applied to w before the hi/lo split
   // training mode (opp_pack_train_weights): the same packing WITHOUT the folded BatchNorm, plus the caller-owned
@@ -61,7 +61,8 @@ struct ConvDesc {  // one packed convolution
   int bn_slot = -1;       // index of that BatchNorm among the backbone's BatchNorm layers (state-dict order)
   int cin_pad() const { return pad32(cin); }
   int cout_pad() const { return pad32(cout); }
-  size_t w_floats() const { return (size_t)cout_pad() * ks * ks * cin_pad(); }
+  int k_len() const { return opp_conv_k(cin, ks); }   // ks*ks*cin_pad, shorter with K tail packing (opp_common.h)
+  size_t w_floats() const { return (size_t)cout_pad() * k_len(); }
 };
 
 struct BlockDesc {
@@ -524,7 +525,8 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.Hout = (Hin + 2 * g.pad - d.ks) / stride + 1;
   g.Wout = (Win + 2 * g.pad - d.ks) / stride + 1;
   g.W = raw ? d.w_train : d.w;
-  g.K = d.ks * d.ks * d.cin_pad();
+  g.K = d.k_len();
+  g.tail_grp = opp_conv_tail_grp(d.cin, d.ks);
   g.ldw = (int)split_floats((size_t)g.K, h2);
   g.M = Bn * g.Hout * g.Wout;
   g.N = d.cout_pad();
@@ -1190,14 +1192,14 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
 // ----------------------------------------------------------------------------------------
 // building blocks
 // ----------------------------------------------------------------------------------------
-extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin_pad, const float* w_packed, const float* bias,
+extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin, const float* w_packed, const float* bias,
                                int cout_pad, int ks, int stride, const float* residual, int res_mode, int act, float* y,
                                int tile_cfg, int prec, const float* h2_scale, void* stream) {
   OPP_CHECK_ARG(x && w_packed && y, "conv2d: null argument");
   OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "conv2d: prec must be 0 (fp32), 1 (fp16x2) or 2 (bf16x3)");
-  OPP_CHECK_ARG(cin_pad % 32 == 0 && cout_pad % 32 == 0, "conv2d: channel counts must be padded to 32");
+  OPP_CHECK_ARG(cin > 0 && cout_pad % 32 == 0, "conv2d: cout_pad must be padded to 32");
   ConvDesc d;
-  d.cin = cin_pad;
+  d.cin = cin;
   d.cout = cout_pad;
   d.ks = ks;
   d.w = const_cast<float*>(w_packed);
@@ -1210,6 +1212,8 @@ extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout
                                     float* out, void* stream) {
   return opp_pack_conv(w, scale, cout, cin, ks, cout_pad, cin_pad, out, (hipStream_t)stream);
 }
+
+extern "C" int opp_conv_packed_k(int cin, int ks) { return opp_conv_k(cin, ks); }
 
 extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {
   OPP_CHECK_ARG(in && out, "pack_h2: null argument");

@@ -29,16 +29,24 @@ __global__ void fold_bn_kernel(const float* __restrict__ gamma, const float* __r
 // optionally * scale[co]
 __global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ scale, int cout,
                                  int cin, int ks, int cout_pad, int cin_pad, float* __restrict__ out) {
-  const int kpad = ks * ks * cin_pad;
+  const int kpad = opp_conv_k(cin, ks);
+  const int tail_grp = opp_conv_tail_grp(cin, ks);
   const size_t total = (size_t)cout_pad * kpad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int co = (int)(i / kpad);
     const int r = (int)(i - (size_t)co * kpad);
     const int taps = ks * ks;
-    const int grp = r / (taps * 32);
+    int grp = r / (taps * 32);
     const int rem = r - grp * taps * 32;
-    const int tap = rem >> 5;
-    const int ci = grp * 32 + (rem & 31);
+    int tap = rem >> 5;
+    int ci = grp * 32 + (rem & 31);
+    if (tail_grp > 0 && grp >= tail_grp) {
+      // K tail: k = tail_grp * taps * 32 + 32 t + 4 q + c  <->  tap 8 t + q, channel 32 tail_grp + c
+      const int rt = r - tail_grp * taps * 32;
+      tap = (rt >> 5) * 8 + ((rt & 31) >> 2);
+      ci = tap < taps ? tail_grp * 32 + (rt & 3) : cin;
+      grp = tail_grp;
+    }
     float v = 0.f;
     if (co < cout && ci < cin) {
       v = w[((size_t)co * cin + ci) * ks * ks + tap];
@@ -190,7 +198,8 @@ int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const 
 
 int opp_pack_conv(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,
                   float* out, hipStream_t stream) {
-  const size_t total = (size_t)cout_pad * ks * ks * cin_pad;
+  OPP_CHECK_ARG(cin_pad == (cin + 31) / 32 * 32, "pack_conv: cin_pad must be cin rounded up to 32");
+  const size_t total = (size_t)cout_pad * opp_conv_k(cin, ks);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, stream, w, scale, cout, cin, ks, cout_pad, cin_pad, out);
   OPP_CHECK_LAUNCH("pack_conv_kernel");

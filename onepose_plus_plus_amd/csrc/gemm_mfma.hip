@@ -163,26 +163,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   int cur_i = 0;                                      // chunks issued so far
   int cur_grp = 0;                                    // channel group (conv) or chunk index (dense)
   int cur_tap = 0, cur_ky = 0, cur_kx = 0;
-  int cur_k0 = CONV ? cur_grp * taps * 32 : cur_grp * 32;
-  unsigned cur_delta = CONV ? (unsigned)(cur_grp * 32) * 4u : 0u;
+  int cur_k0 = 0;
   unsigned cur_past = 0;
+  // conv: byte offset of the chunk's (tap, channel group) from a_base0 and the shift that brings the
+  // tap's invalid-bit to bit 31.  Per lane only in the K tail (g.tail_grp > 0: the last <= 4 real
+  // channels of a Cin = 32 n + 4 input, e.g. 196, are packed 8 taps to a chunk - lane quarter kq
+  // carries tap 8 t + kq - instead of one mostly-zero 32-channel chunk per tap: 9 chunks -> 2).
+  unsigned eff_delta = 0, eff_sh = 31;
+  int tail_i = -1;                                    // >= 0: index of the current tail chunk
+  const int kq_lane = tid & 7;
+  auto tail_lane = [&](int t, unsigned& delta, unsigned& sh) {
+    const int tp = t * 8 + kq_lane;                   // taps >= ksize^2 have their invalid-bit set
+    const int ty = tp / g.ksize, tx = tp - ty * g.ksize;
+    delta = (unsigned)((ty * g.Win + tx) * g.Cin + g.tail_grp * 32 - kq_lane * 4) * 4u;
+    sh = (unsigned)(31 - tp);
+  };
   auto advance = [&]() {
     ++cur_i;
     cur_past = cur_i < nk ? 0u : kOob;
     if (CONV) {
-      ++cur_tap;
-      if (++cur_kx == g.ksize) {
-        cur_kx = 0;
-        ++cur_ky;
+      cur_k0 = cur_i * 32;                            // the packed K order is the chunk order
+      if (tail_i < 0) {
+        ++cur_tap;
+        if (++cur_kx == g.ksize) {
+          cur_kx = 0;
+          ++cur_ky;
+        }
+        if (cur_tap == taps) {
+          cur_tap = 0;
+          cur_ky = 0;
+          cur_kx = 0;
+          ++cur_grp;
+          if (g.tail_grp > 0 && cur_grp == g.tail_grp) tail_i = 0;
+          else if (cur_grp == ngrp) cur_grp = 0;
+        }
+      } else {
+        ++tail_i;
       }
-      if (cur_tap == taps) {
-        cur_tap = 0;
-        cur_ky = 0;
-        cur_kx = 0;
-        if (++cur_grp == ngrp) cur_grp = 0;
+      if (tail_i < 0) {
+        eff_delta = (unsigned)((cur_ky * g.Win + cur_kx) * g.Cin + cur_grp * 32) * 4u;
+        eff_sh = (unsigned)(31 - cur_tap);
+      } else {
+        tail_lane(tail_i & 1, eff_delta, eff_sh);     // chunks past the end are killed by cur_past
       }
-      cur_k0 = (cur_grp * taps + cur_tap) * 32;
-      cur_delta = (unsigned)((cur_ky * g.Win + cur_kx) * g.Cin + cur_grp * 32) * 4u;
     } else {
       if (++cur_grp == ngrp) cur_grp = 0;
       cur_k0 = cur_grp * 32;
@@ -203,8 +226,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         // pure data flow (no exec masking): a_mask holds the INVALID taps, so shifting the current
         // tap's bit to bit 31 yields the out-of-range offset directly (shift, add, and-or per load)
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, live ? g.a0_bytes : 0, 0x00020000);
-        const unsigned bad = a_mask[i] << (31 - cur_tap);
-        a_reg[i] = bload(r, (bad & kOob) | (a_base0[i] + cur_delta));
+        const unsigned bad = a_mask[i] << eff_sh;
+        a_reg[i] = bload(r, (bad & kOob) | (a_base0[i] + eff_delta));
       } else if (cur_k0 < g.ksplit) {
         // (kOob + small) stays out of range, so invalid rows need no select
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A0), 0, live ? g.a0_bytes : 0, 0x00020000);
@@ -1070,7 +1093,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   OPP_CHECK_ARG((size_t)g.N * g.ldw * 4 < (1ull << 31), "gemm: weight operand too large for buffer addressing");
   OPP_CHECK_ARG(g.prec != OPP_PREC_BF16X3 || g.ldw * 2 >= g.K * 3, "gemm: bf16x3 weights need a row stride of 1.5 K floats");
   if (g.conv) {
-    OPP_CHECK_ARG(g.Cin % 32 == 0 && g.K == g.ksize * g.ksize * g.Cin, "conv: Cin %% 32 / K mismatch");
+    const int k_expect = g.tail_grp > 0 ? (g.tail_grp * g.ksize * g.ksize + (g.ksize * g.ksize + 7) / 8) * 32 : g.ksize * g.ksize * g.Cin;
+    OPP_CHECK_ARG(g.Cin % 32 == 0 && g.K == k_expect, "conv: Cin %% 32 / K mismatch");
+    OPP_CHECK_ARG(g.tail_grp == 0 || (g.ksize == 3 && g.tail_grp == g.Cin / 32 - 1), "conv: K tail packing needs a 3x3 kernel and one partial channel group");
     OPP_CHECK_ARG(g.M == g.Bn * g.Hout * g.Wout, "conv: M != B*Hout*Wout");
     const size_t ab = (size_t)g.Bn * g.Hin * g.Win * g.Cin * 4;
     OPP_CHECK_ARG(ab < (1ull << 31), "conv: input too large for buffer addressing");

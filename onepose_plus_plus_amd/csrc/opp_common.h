@@ -56,6 +56,17 @@ enum { OPP_PREC_FP32 = 0, OPP_PREC_FP16X2 = 1, OPP_PREC_BF16X3 = 2 };
 enum { OPP_TILES_LATENCY = 0, OPP_TILES_THROUGHPUT = 1 };
 enum { OPP_RES_NONE = 0, OPP_RES_DIRECT = 1, OPP_RES_BILINEAR2X = 2 };
 
+// K tail packing of a 3x3 convolution whose input has 32 n + (1..4) channels (the 196-channel stage of the backbone):
+// the n full channel groups are walked tap by tap as usual, the last <= 4 channels of ALL taps are packed 8 taps to a
+// 32-wide chunk (k = 4 * (tap % 8) + c), so that K is (9 n + 2) * 32 instead of 9 (n + 1) * 32.
+// Returns n (the number of full groups) when the packing applies, else 0.
+__host__ __device__ inline int opp_conv_tail_grp(int cin, int ks) { return (ks == 3 && cin > 32 && cin % 32 >= 1 && cin % 32 <= 4) ? cin / 32 : 0; }
+// length of one packed weight row
+__host__ __device__ inline int opp_conv_k(int cin, int ks) {
+  const int tg = opp_conv_tail_grp(cin, ks);
+  return tg ? (tg * ks * ks + (ks * ks + 7) / 8) * 32 : ks * ks * ((cin + 31) / 32 * 32);
+}
+
 struct OppGemm {
   // A operand -- dense mode
   const float* A0 = nullptr;
@@ -65,6 +76,7 @@ struct OppGemm {
   // A operand -- conv mode (A0 = NHWC input [B][Hin][Win][Cin], Cin % 32 == 0)
   int conv = 0;
   int Bn = 1, Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, ksize = 1, stride = 1, pad = 0;
+  int tail_grp = 0;  // > 0: K tail packing (opp_conv_tail_grp), the first tail_grp channel groups are full
   // B operand: weights [N][K] row-major (row stride ldw)
   const float* W = nullptr;
   int ldw = 0;

@@ -97,7 +97,7 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
     H, W = x_nchw.shape[2:]
     pad = ks // 2
     Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
-    wp = torch.empty(cout_p * ks * ks * cin_p, device="cuda")
+    wp = torch.empty(cout_p * lib.opp_conv_packed_k(cin, ks), device="cuda")
     wd = w.cuda().contiguous()
     sd = None
     if scale is not None:
@@ -114,7 +114,7 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
     if residual is not None:
         rd = to_nhwc_padded(residual, cout_p)
     y = torch.full((Ho, Wo, cout_p), float("nan"), device="cuda")
-    _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin_p, wp.data_ptr(), bd.data_ptr() if bd is not None else None,
+    _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, wp.data_ptr(), bd.data_ptr() if bd is not None else None,
                                    cout_p, ks, stride, rd.data_ptr() if rd is not None else None, res_mode, act,
                                    y.data_ptr(), cfg, _prec(h2), sc.data_ptr() if sc is not None else None, _s()),
                "conv2d")

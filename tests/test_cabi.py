@@ -76,3 +76,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.OppError):
         _lib.load()
+
+
+def test_conv_packed_k(lib):
+    """Host-only size query: ks*ks*pad32(cin), or the K-tail packing (n full groups x 9 taps + 2 tail chunks)."""
+    assert lib.opp_conv_packed_k(128, 3) == 9 * 128
+    assert lib.opp_conv_packed_k(196, 3) == (6 * 9 + 2) * 32
+    assert lib.opp_conv_packed_k(196, 1) == 224
+    assert lib.opp_conv_packed_k(97, 3) == (3 * 9 + 2) * 32
+    assert lib.opp_conv_packed_k(101, 3) == 9 * 128        # five tail channels do not fit 4 per tap
+    assert lib.opp_conv_packed_k(4, 3) == 9 * 32           # no full group to attach the tail to

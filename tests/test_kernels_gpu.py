@@ -156,6 +156,11 @@ CONV_CASES = [
     (196, 256, 1, 1, 16, 24),
     (256, 196, 3, 1, 10, 12),
     (256, 256, 3, 1, 8, 8),
+    # K tail packing (3x3 over 32 n + 1..4 channels: the last channels of all taps share two chunks)
+    (196, 128, 3, 2, 17, 23),
+    (68, 64, 3, 1, 9, 33),
+    (97, 64, 3, 1, 12, 12),
+    (101, 64, 3, 1, 12, 12),      # 5 tail channels: NOT packed
 ]
 
 

@@ -80,7 +80,7 @@ def main():
             continue
         cip, cop = pad32(cin), pad32(cout)
         x = torch.randn(H, W, cip, device="cuda")
-        w = torch.randn(cop, ks * ks * cip, device="cuda") * 0.02
+        w = torch.randn(cop, lib.opp_conv_packed_k(cin, ks), device="cuda") * 0.02
         Ho, Wo = H // stride, W // stride
         y = torch.empty(Ho, Wo, cop, device="cuda")
         bias = torch.randn(cop, device="cuda")
@@ -96,7 +96,7 @@ def main():
                 continue
 
             def fn():
-                _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cip, w.data_ptr(), bias.data_ptr(), cop, ks, stride,
+                _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, w.data_ptr(), bias.data_ptr(), cop, ks, stride,
                                                None, 0, 1, y.data_ptr(), cfg, args.prec, None, s), "conv")
             try:
                 us = timeit(fn, args.iters)
