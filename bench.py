@@ -446,23 +446,38 @@ def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):
         fwd()
     torch.cuda.synchronize(dev)
     full_ms = (time.perf_counter() - t) / nsteps * 1e3
-    _lib.check(lib.opp_profile_start(1003, 0, nsteps * 40), "profile_start")
-    for _ in range(nsteps):
-        fwd()
-    torch.cuda.synchronize(dev)
-    ms, by, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-    _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(by), ctypes.byref(nl)), "profile_stop")
+
+    def span(symbol):
+        """HIP-event time / algorithmic bytes / launches of one profiler symbol over nsteps forwards."""
+        _lib.check(lib.opp_profile_start(symbol, 0, nsteps * 40), "profile_start")
+        for _ in range(nsteps):
+            fwd()
+        torch.cuda.synchronize(dev)
+        ms, by, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(by), ctypes.byref(nl)), "profile_stop")
+        return ms.value / nsteps, by.value / nsteps, nl.value / nsteps
+
     out = {"workload": "full coarse-to-fine forward, %dx%d x %d points, thr %.1f, bank optimised for confident matches "
                        "(tests/golden/%s.npz), single stream" % (hw[0], hw[1], n, thr, name),
            "matches": M, "ms_per_forward": round(full_ms, 3), "images_per_s": round(1e3 / full_ms, 2)}
-    if nl.value > 0 and ms.value > 0:
-        fine_ms = ms.value / nsteps
-        gather_bytes = M * 25 * 128 * 4.0
-        out.update({"fine_stage_ms": round(fine_ms, 4), "fine_stage_launches_per_forward": round(nl.value / nsteps, 1),
-                    "fine_ms_per_1000_matches": round(fine_ms / max(M, 1) * 1000, 4),
-                    "window_gather_mbytes": round(gather_bytes / 1e6, 2),
-                    "fine_stage_alg_gbs": round(by.value / nsteps / (fine_ms * 1e-3) / 1e9, 1),
-                    "fine_stage_frac_of_hbm_peak": round(by.value / nsteps / (fine_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)})
+    fine_ms, _, nl = span(1003)
+    if nl > 0 and fine_ms > 0:
+        # SURVEY 8(d): the fine level is 17.47 MFLOP per match (window transformer, C = 128) -> MFMA-bound as a whole;
+        # its gather / attention / head kernels are HBM-bound and reported against the HBM peak on their own
+        gflop = M * 17.47e6 / 1e9
+        out.update({"fine_stage_ms": round(fine_ms, 4), "fine_ms_per_1000_matches": round(fine_ms / max(M, 1) * 1000, 4),
+                    "fine_stage_alg_gflop": round(gflop, 2), "fine_stage_tflops": round(gflop / fine_ms, 2),
+                    "fine_stage_frac_of_mfma_peak": round(gflop / fine_ms / MFMA_PEAK[precision], 4), "kernels": []})
+        for sym, label in ((1005, "fine_gather_kernel (5x5 windows + point descriptors, read + written once)"),
+                           (1004, "linattn_small_pair_kernel (fine-level linear attention: Q, K, V read, message written)"),
+                           (1006, "fine_head_kernel (windows + point tokens read once)")):
+            ms, by, k = span(sym)
+            if k > 0 and ms > 0:
+                gbs = by / (ms * 1e-3) / 1e9
+                out["kernels"].append({"kernel": label, "bound": "hbm", "launches_per_forward": round(k, 1),
+                                       "avg_launch_us": round(ms / k * 1e3, 2), "alg_mbytes_per_launch": round(by / k / 1e6, 2),
+                                       "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                       "frac": round(gbs / PEAK_HBM_GBS, 4)})
     return out
 
 

@@ -914,12 +914,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     const bool cross = is_cross[li] != 0;
     {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
       OppGemm g;
-    g.nonfinite = t_status_flag;
-  g.tile_policy = t_tile_policy;
       g.nonfinite = t_status_flag;
-  g.tile_policy = t_tile_policy;
-  g.nonfinite = t_status_flag;
-  g.tile_policy = t_tile_policy;
+      g.tile_policy = t_tile_policy;
       g.A0 = X;
       g.lda0 = C;
       g.ksplit = C;
@@ -947,6 +943,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     if (n_seg == 1 && C == 256 && D == 32) {   // coarse level: MFMA KV reduction, both streams per launch
       OPP_TRY(opp_linattn_kv_pair(b.qkv, 3 * C, len0, len1, kv0, ks0, b.scratch, s));
       OPP_TRY(opp_linattn_apply_pair(b.qkv, 3 * C, kv0, ks0, cross ? 1 : 0, b.msg, C, len0, len1, eps_attn, s));
+    } else if (opp_linattn_small_ok(len0, len1, C, D)) {   // fine level: one launch, KV never leaves the CU
+      OPP_TRY(opp_linattn_small_pair(b.qkv, 3 * C, n_seg, len0, len1, cross ? 1 : 0, b.msg, C, C, D, eps_attn, s));
     } else {
     OPP_TRY(opp_linattn_kv(q0 + C, q0 + 2 * C, 3 * C, n_seg, len0, C, D, kv0, ks0, b.scratch, s));
     OPP_TRY(opp_linattn_kv(q1 + C, q1 + 2 * C, 3 * C, n_seg, len1, C, D, kv1, ks1, b.scratch, s));

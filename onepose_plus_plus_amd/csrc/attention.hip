@@ -235,6 +235,105 @@ __global__ __launch_bounds__(C) void linattn_apply_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// Fine level (n_seg = M matches, 25 window tokens + 1 point token each, C = 128, D = 16): the whole linear attention
+// of one segment pair in one workgroup.  Q | K | V of the pair's tokens are staged in LDS with coalesced 16-byte
+// loads (39 KB for 26 tokens), thread t <-> (head h = t / D, column v = t % D) keeps KV[h][.][v] of both streams in
+// registers - it is exactly the slice the apply needs, so KV never goes to memory; Ksum crosses threads through LDS.
+// Same arithmetic, in the same order, as linattn_kv_partial_kernel + linattn_apply_kernel (bit-identical results).
+//   qkv rows: stream 0 = seg * len0 + l, stream 1 = n_seg * len0 + seg * len1 + l ; out rows likewise
+// ---------------------------------------------------------------------------------------
+template <int D, int C>
+__global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __restrict__ qkv, int ld, int n_seg, int len0,
+                                                               int len1, int cross, float* __restrict__ out, int ldo,
+                                                               float eps) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // [len0 + len1][3 C] then Ksum [2][C]
+  const int t = threadIdx.x;
+  const int h = t / D;
+  const int seg = blockIdx.x;
+  const int rows = len0 + len1;
+  const size_t row0 = (size_t)seg * len0, row1 = (size_t)n_seg * len0 + (size_t)seg * len1;
+  constexpr int PER_ROW = 3 * C / 4;
+  float4* sh4 = reinterpret_cast<float4*>(sh);
+  for (int e = t; e < rows * PER_ROW; e += C) {
+    const int r = e / PER_ROW, c4 = e - r * PER_ROW;
+    const size_t grow = r < len0 ? row0 + r : row1 + (r - len0);
+    sh4[e] = *reinterpret_cast<const float4*>(qkv + grow * ld + c4 * 4);
+  }
+  __syncthreads();
+  float kv[2][D];
+  float* ks_sh = sh + (size_t)rows * 3 * C;   // Ksum [2][C]
+  float* z_sh = ks_sh + 2 * C;                // 1 / (Q . Ksum + eps) per (token, head)
+  constexpr int H = C / D;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) kv[st][d] = 0.f;
+    float ksum = 0.f;
+    const int r_begin = st ? len0 : 0, r_end = st ? rows : len0;
+#pragma unroll 5
+    for (int r = r_begin; r < r_end; ++r) {
+      const float* row = sh + (size_t)r * 3 * C;
+      const float vv = row[2 * C + t];
+      ksum += row[C + t];
+      const float4* kr = reinterpret_cast<const float4*>(row + C + h * D);
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 k4 = kr[d4];
+        kv[st][d4 * 4 + 0] = fmaf(k4.x, vv, kv[st][d4 * 4 + 0]);
+        kv[st][d4 * 4 + 1] = fmaf(k4.y, vv, kv[st][d4 * 4 + 1]);
+        kv[st][d4 * 4 + 2] = fmaf(k4.z, vv, kv[st][d4 * 4 + 2]);
+        kv[st][d4 * 4 + 3] = fmaf(k4.w, vv, kv[st][d4 * 4 + 3]);
+      }
+    }
+    ks_sh[st * C + t] = ksum;
+  }
+  __syncthreads();
+  // self: each stream attends to itself; cross: to the other stream's K, V.  The normaliser is the same for the D
+  // columns of a head: one thread per (token, head) computes it
+  for (int e = t; e < rows * H; e += C) {
+    const int r = e / H, hh = e - r * H;
+    const int src = (r < len0 ? 0 : 1) ^ (cross ? 1 : 0);
+    const float4* qr = reinterpret_cast<const float4*>(sh + (size_t)r * 3 * C + hh * D);
+    const float4* kr = reinterpret_cast<const float4*>(ks_sh + src * C + hh * D);
+    float den = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+      const float4 q4 = qr[d4], k4 = kr[d4];
+      den = fmaf(q4.x, k4.x, den);
+      den = fmaf(q4.y, k4.y, den);
+      den = fmaf(q4.z, k4.z, den);
+      den = fmaf(q4.w, k4.w, den);
+    }
+    z_sh[e] = 1.0f / (den + eps);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int src = cross ? 1 - st : st;
+    const float src_len = (float)(src ? len1 : len0);
+    const int r_begin = st ? len0 : 0, r_end = st ? rows : len0;
+    float kvs[D];   // compile-time register indices only
+#pragma unroll
+    for (int d = 0; d < D; ++d) kvs[d] = cross ? kv[1 - st][d] : kv[st][d];
+#pragma unroll 5
+    for (int r = r_begin; r < r_end; ++r) {
+      const float4* qr = reinterpret_cast<const float4*>(sh + (size_t)r * 3 * C + h * D);
+      float num = 0.f;
+#pragma unroll
+      for (int d4 = 0; d4 < D / 4; ++d4) {
+        const float4 q4 = qr[d4];
+        num = fmaf(q4.x, kvs[d4 * 4 + 0], num);
+        num = fmaf(q4.y, kvs[d4 * 4 + 1], num);
+        num = fmaf(q4.z, kvs[d4 * 4 + 2], num);
+        num = fmaf(q4.w, kvs[d4 * 4 + 3], num);
+      }
+      const size_t grow = st ? row1 + (r - len0) : row0 + r;
+      out[grow * ldo + t] = (num * z_sh[r * H + h]) * src_len;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Coarse level (one segment per stream, C = 256, D = 32): KV / Ksum on the fp32 MFMA.
 // One block = one wave = one head of one chunk of kPairChunk tokens of ONE stream (grid = chunks x 8 heads,
 // >= 4 waves per CU at 5k points: the reduction is bound by loads in flight, not by the MFMA):
@@ -451,6 +550,23 @@ int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks,
   return OPP_OK;
 }
 
+
+bool opp_linattn_small_ok(int len0, int len1, int C, int D) {
+  return C == 128 && D == 16 && len0 > 0 && len1 > 0 && len0 + len1 <= 32;
+}
+
+int opp_linattn_small_pair(const float* qkv, int ld, int n_seg, int len0, int len1, int cross, float* out, int ldo, int C, int D,
+                           float eps, hipStream_t stream) {
+  if (n_seg <= 0) return OPP_OK;
+  OPP_CHECK_ARG(opp_linattn_small_ok(len0, len1, C, D) && ld % 4 == 0, "linattn_small_pair: unsupported shape");
+  const size_t lds = ((size_t)(len0 + len1) * 3 * C + 2 * C + (size_t)(len0 + len1) * (C / D)) * sizeof(float);
+  // algorithmic bytes: Q, K, V of every token read once, the message written once
+  OppProfScope prof(OPP_PROF_LINATTN_SMALL, stream, (double)n_seg * (len0 + len1) * C * 4.0 * 4.0);
+  hipLaunchKernelGGL((linattn_small_pair_kernel<16, 128>), dim3(n_seg), dim3(128), lds, stream, qkv, ld, n_seg, len0, len1, cross, out,
+                     ldo, eps);
+  OPP_CHECK_LAUNCH("linattn_small_pair_kernel");
+  return OPP_OK;
+}
 
 // ---- coarse level: both streams in three launches ------------------------------------------
 size_t opp_linattn_pair_scratch_floats(int len0, int len1) {

@@ -9,6 +9,7 @@
 // The gather is HBM-bound: M * W*W * C * 4 bytes (12.8 KB per match) read from the NHWC fine
 // feature map with lanes along the channel axis (512 B contiguous per window cell).
 #include "opp_common.h"
+#include "opp_internal.h"
 
 namespace {
 
@@ -24,13 +25,16 @@ __global__ __launch_bounds__(128) void fine_gather_kernel(const float* __restric
   const int jy = j / wc, jx = j - jy * wc;
   const int cy = jy * stride - Wwin / 2, cx = jx * stride - Wwin / 2;
   const int WW = Wwin * Wwin;
-  for (int e = threadIdx.x; e < WW * C; e += blockDim.x) {
-    const int r = e / C, c = e - r * C;
+  // one 16-byte load per lane: a window cell is C * 4 contiguous bytes of the NHWC map (C % 4 == 0 checked by the launcher)
+  const int c4n = C >> 2;
+  for (int e = threadIdx.x; e < WW * c4n; e += blockDim.x) {
+    const int r = e / c4n, c = (e - r * c4n) * 4;
     const int ky = r / Wwin, kx = r - ky * Wwin;
     const int y = cy + ky, x = cx + kx;
-    float v = 0.f;
-    if ((unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf) v = feat[((size_t)y * Wf + x) * ldf + c];
-    win[((size_t)m * WW + r) * ldw + c] = v;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf)
+      v = *reinterpret_cast<const float4*>(feat + ((size_t)y * Wf + x) * ldf + c);
+    *reinterpret_cast<float4*>(win + ((size_t)m * WW + r) * ldw + c) = v;
   }
   const long long i = i_ids[m];
   for (int c = threadIdx.x; c < C; c += blockDim.x) f3[(size_t)m * ld3 + c] = bank[(size_t)c * n_points + i];
@@ -43,17 +47,36 @@ __global__ __launch_bounds__(256) void fine_head_kernel(const float* __restrict_
                                                         const float* __restrict__ qscale,
                                                         float* __restrict__ expec, float* __restrict__ mkpts_f) {
   const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
+  const int m_raw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = m_raw < M;              // waves past the end redo the last match and store nothing
+  const int m = live ? m_raw : M - 1;
   const int WW = Wwin * Wwin;   // <= 64 handled by one lane per cell
-  float sim = -INFINITY;
-  if (lane < WW) {
-    const float* w = win + ((size_t)m * WW + lane) * ldw;
-    const float* f = f3 + (size_t)m * ld3;
+  // similarities with 16 lanes per window cell (8 channels each, 16-byte loads: a wave reads 4 cells = 2 KB per pass),
+  // then handed to lane = cell through LDS for the softmax / expectation below
+  __shared__ float sim_sh[4][64];
+  const int wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
+  for (int r0 = 0; r0 < WW; r0 += 4) {
+    const int r = r0 + grp;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(f[c], w[c], acc);
-    sim = temp * acc;   // softmax_temp * sim_matrix, fine_matching.py:82-83
+    if (r < WW) {
+      const float* w = win + ((size_t)m * WW + r) * ldw;
+      const float* f = f3 + (size_t)m * ld3;
+      for (int c = sub * 4; c < C; c += 64) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + c);
+        const float4 f4 = *reinterpret_cast<const float4*>(f + c);
+        acc = fmaf(f4.x, w4.x, acc);
+        acc = fmaf(f4.y, w4.y, acc);
+        acc = fmaf(f4.z, w4.z, acc);
+        acc = fmaf(f4.w, w4.w, acc);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0 && r < WW) sim_sh[wv][r] = acc;
   }
+  __syncthreads();
+  float sim = -INFINITY;
+  if (lane < WW) sim = temp * sim_sh[wv][lane];   // softmax_temp * sim_matrix, fine_matching.py:82-83
   float mx = sim;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -77,7 +100,7 @@ __global__ __launch_bounds__(256) void fine_head_kernel(const float* __restrict_
     exx += __shfl_xor(exx, o, 64);
     eyy += __shfl_xor(eyy, o, 64);
   }
-  if (lane == 0) {
+  if (lane == 0 && live) {
     const float vx = fmaxf(exx - ex * ex, 1e-10f);
     const float vy = fmaxf(eyy - ey * ey, 1e-10f);
     expec[3 * m + 0] = ex;
@@ -98,6 +121,9 @@ int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* ban
                     const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,
                     float* win, int ldw, float* f3, int ld3, hipStream_t stream) {
   if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(C % 4 == 0 && ldf % 4 == 0 && ldw % 4 == 0, "fine gather: channel counts / strides must be multiples of 4");
+  // algorithmic bytes: windows read + written, point descriptors read + written
+  OppProfScope prof(OPP_PROF_FINE_GATHER, stream, (double)M * (Wwin * Wwin + 1) * C * 4.0 * 2.0);
   hipLaunchKernelGGL(fine_gather_kernel, dim3(M), dim3(128), 0, stream, feat, Hf, Wf, ldf, bank, n_points, i_ids, j_ids, wc,
                      stride, Wwin, C, win, ldw, f3, ld3);
   OPP_CHECK_LAUNCH("fine_gather_kernel");
@@ -109,6 +135,8 @@ int opp_fine_head(const float* f3, int ld3, const float* win, int ldw, int M, in
                   hipStream_t stream) {
   if (M <= 0) return OPP_OK;
   OPP_CHECK_ARG(Wwin * Wwin <= 64, "fine head: window %d too large", Wwin);
+  OPP_CHECK_ARG(C % 4 == 0 && ldw % 4 == 0 && ld3 % 4 == 0, "fine head: channel counts / strides must be multiples of 4");
+  OppProfScope prof(OPP_PROF_FINE_HEAD, stream, (double)M * (Wwin * Wwin + 1) * C * 4.0);   // windows + point tokens read once
   hipLaunchKernelGGL(fine_head_kernel, dim3(opp_cdiv(M, 4)), dim3(256), 0, stream, f3, ld3, win, ldw, M, Wwin, C, temp, mkpts_c,
                      base_scale, qscale, expec, mkpts_f);
   OPP_CHECK_LAUNCH("fine_head_kernel");

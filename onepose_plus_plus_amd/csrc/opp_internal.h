@@ -11,6 +11,9 @@ enum {
   OPP_PROF_LINATTN_APPLY = 1001,   // linattn_apply_pair_kernel
   OPP_PROF_CONF = 1002,            // conf_reg_kernel: dual-softmax product over the N x L score matrix
   OPP_PROF_FINE = 1003,            // fine stage kernel(s)
+  OPP_PROF_LINATTN_SMALL = 1004,   // linattn_small_pair_kernel: fine-level attention, one workgroup per match
+  OPP_PROF_FINE_GATHER = 1005,     // fine_gather_kernel
+  OPP_PROF_FINE_HEAD = 1006,       // fine_head_kernel
 };
 inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
 struct OppProfScope {
@@ -35,6 +38,11 @@ int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks,
 size_t opp_linattn_pair_scratch_floats(int len0, int len1);
 int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
                         hipStream_t stream);
+// many short segment pairs (fine level: 25 window tokens + 1 point token per match): KV, Ksum and the apply of both
+// streams of one segment in one workgroup
+bool opp_linattn_small_ok(int len0, int len1, int C, int D);
+int opp_linattn_small_pair(const float* qkv, int ld, int n_seg, int len0, int len1, int cross, float* out, int ldo, int C, int D,
+                           float eps, hipStream_t stream);
 int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
                            int len0, int len1, float eps, hipStream_t stream);
 // backbone.hip
