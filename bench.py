@@ -413,7 +413,63 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
         legs["fine_leg"] = fine_leg(torch, dev, precision, lib, _lib)
     except Exception as e:      # the fixture is optional for the headline
         legs["fine_leg"] = {"error": str(e)}
+    try:
+        legs["train_leg"] = train_leg(torch, dev, precision)
+    except Exception as e:
+        legs["train_leg"] = {"error": str(e)}
     return legs
+
+
+def train_leg(torch, dev, precision, nsteps=2):
+    """One training step at the per-GPU shape of BASELINE configs[4] (B = 4, 512x512, N = 7000 points padded as the
+    reference's dataset does, train.yaml:185,194): train()-mode forward on the HIP path (BatchNorm batch statistics,
+    training branch of get_coarse_match, fine level on the padded matches), a focal-style scalar on conf_matrix +
+    expec_f, backward (PyTorch ops re-evaluating the graph, onepose_plus_plus_amd/train_autograd.py) and an SGD update."""
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    B, N, hw = 4, 7000, (512, 512)
+    cfg = default_config(thr=0.2)
+    model = OnePosePlus_model(cfg).set_gemm_precision(precision).to(dev)
+    model.load_state_dict(make_state_dict(cfg, 0), strict=True)
+    model.train()
+    parts = [make_inputs(N, hw, 30 + b) for b in range(B)]
+    base = {k: torch.cat([p[k] for p in parts], 0).to(dev) for k in parts[0]}
+    g = torch.Generator().manual_seed(9)
+    gt = torch.zeros(B, N, 4096, dtype=torch.int16)
+    for b in range(B):
+        gt[b, torch.randperm(N, generator=g)[:1500], torch.randperm(4096, generator=g)[:1500]] = 1
+    base["conf_matrix_gt"] = gt.to(dev)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5)
+
+    def fwd_only():
+        d = dict(base)
+        with torch.no_grad():
+            model(d)
+
+    def full_step():
+        d = dict(base)
+        model(d)
+        loss = -(torch.log(d["conf_matrix"][d["conf_matrix_gt"] == 1].clamp(1e-6))).mean() + (d["expec_f"][:, :2] ** 2).sum(-1).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            r = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / nsteps * 1e3, r
+
+    fwd_ms, _ = timed(fwd_only)
+    step_ms, loss = timed(full_step)
+    return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, 7000 points, train() mode, single stream",
+            "forward_ms": round(fwd_ms, 2), "forward_samples_per_s": round(B / fwd_ms * 1e3, 1),
+            "step_ms": round(step_ms, 1), "step_samples_per_s": round(B / step_ms * 1e3, 2), "loss": round(loss, 5),
+            "note": "forward = hand-written HIP path; backward = PyTorch ops on the device (not hand-written yet)"}
 
 
 def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):

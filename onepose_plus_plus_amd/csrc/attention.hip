@@ -246,24 +246,24 @@ template <int D, int C>
 __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __restrict__ qkv, int ld, int n_seg, int len0,
                                                                int len1, int cross, float* __restrict__ out, int ldo,
                                                                float eps) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];   // [len0 + len1][3 C] then Ksum [2][C]
+  extern __shared__ __attribute__((aligned(16))) float sh[];   // K | V [len0 + len1][2 C], Ksum [2][C], z [rows][H]
   const int t = threadIdx.x;
   const int h = t / D;
   const int seg = blockIdx.x;
   const int rows = len0 + len1;
   const size_t row0 = (size_t)seg * len0, row1 = (size_t)n_seg * len0 + (size_t)seg * len1;
-  constexpr int PER_ROW = 3 * C / 4;
+  auto grow = [&](int r) -> size_t { return r < len0 ? row0 + r : row1 + (r - len0); };
+  constexpr int PER_ROW = 2 * C / 4;
+  constexpr int H = C / D;
   float4* sh4 = reinterpret_cast<float4*>(sh);
   for (int e = t; e < rows * PER_ROW; e += C) {
     const int r = e / PER_ROW, c4 = e - r * PER_ROW;
-    const size_t grow = r < len0 ? row0 + r : row1 + (r - len0);
-    sh4[e] = *reinterpret_cast<const float4*>(qkv + grow * ld + c4 * 4);
+    sh4[e] = *reinterpret_cast<const float4*>(qkv + grow(r) * ld + C + c4 * 4);
   }
   __syncthreads();
   float kv[2][D];
-  float* ks_sh = sh + (size_t)rows * 3 * C;   // Ksum [2][C]
-  float* z_sh = ks_sh + 2 * C;                // 1 / (Q . Ksum + eps) per (token, head)
-  constexpr int H = C / D;
+  float* ks_sh = sh + (size_t)rows * 2 * C;
+  float* z_sh = ks_sh + 2 * C;
 #pragma unroll
   for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -272,10 +272,10 @@ __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __re
     const int r_begin = st ? len0 : 0, r_end = st ? rows : len0;
 #pragma unroll 5
     for (int r = r_begin; r < r_end; ++r) {
-      const float* row = sh + (size_t)r * 3 * C;
-      const float vv = row[2 * C + t];
-      ksum += row[C + t];
-      const float4* kr = reinterpret_cast<const float4*>(row + C + h * D);
+      const float* row = sh + (size_t)r * 2 * C;
+      const float vv = row[C + t];
+      ksum += row[t];
+      const float4* kr = reinterpret_cast<const float4*>(row + h * D);
 #pragma unroll
       for (int d4 = 0; d4 < D / 4; ++d4) {
         const float4 k4 = kr[d4];
@@ -289,11 +289,13 @@ __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __re
   }
   __syncthreads();
   // self: each stream attends to itself; cross: to the other stream's K, V.  The normaliser is the same for the D
-  // columns of a head: one thread per (token, head) computes it
+  // columns of a head: one thread per (token, head) computes it.  Q comes straight from memory (the 16 lanes of a
+  // head share one 64-byte segment): staging only K and V keeps the footprint at 27 KB -> every match of a
+  // 1500-match image is resident at once
   for (int e = t; e < rows * H; e += C) {
     const int r = e / H, hh = e - r * H;
     const int src = (r < len0 ? 0 : 1) ^ (cross ? 1 : 0);
-    const float4* qr = reinterpret_cast<const float4*>(sh + (size_t)r * 3 * C + hh * D);
+    const float4* qr = reinterpret_cast<const float4*>(qkv + grow(r) * ld + hh * D);
     const float4* kr = reinterpret_cast<const float4*>(ks_sh + src * C + hh * D);
     float den = 0.f;
 #pragma unroll
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __re
     for (int d = 0; d < D; ++d) kvs[d] = cross ? kv[1 - st][d] : kv[st][d];
 #pragma unroll 5
     for (int r = r_begin; r < r_end; ++r) {
-      const float4* qr = reinterpret_cast<const float4*>(sh + (size_t)r * 3 * C + h * D);
+      const size_t g = grow(r);
+      const float4* qr = reinterpret_cast<const float4*>(qkv + g * ld + h * D);
       float num = 0.f;
 #pragma unroll
       for (int d4 = 0; d4 < D / 4; ++d4) {
@@ -327,8 +330,7 @@ __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __re
         num = fmaf(q4.z, kvs[d4 * 4 + 2], num);
         num = fmaf(q4.w, kvs[d4 * 4 + 3], num);
       }
-      const size_t grow = st ? row1 + (r - len0) : row0 + r;
-      out[grow * ldo + t] = (num * z_sh[r * H + h]) * src_len;
+      out[g * ldo + t] = (num * z_sh[r * H + h]) * src_len;
     }
   }
 }
@@ -559,7 +561,7 @@ int opp_linattn_small_pair(const float* qkv, int ld, int n_seg, int len0, int le
                            float eps, hipStream_t stream) {
   if (n_seg <= 0) return OPP_OK;
   OPP_CHECK_ARG(opp_linattn_small_ok(len0, len1, C, D) && ld % 4 == 0, "linattn_small_pair: unsupported shape");
-  const size_t lds = ((size_t)(len0 + len1) * 3 * C + 2 * C + (size_t)(len0 + len1) * (C / D)) * sizeof(float);
+  const size_t lds = ((size_t)(len0 + len1) * 2 * C + 2 * C + (size_t)(len0 + len1) * (C / D)) * sizeof(float);
   // algorithmic bytes: Q, K, V of every token read once, the message written once
   OppProfScope prof(OPP_PROF_LINATTN_SMALL, stream, (double)n_seg * (len0 + len1) * C * 4.0 * 4.0);
   hipLaunchKernelGGL((linattn_small_pair_kernel<16, 128>), dim3(n_seg), dim3(128), lds, stream, qkv, ld, n_seg, len0, len1, cross, out,
