@@ -418,17 +418,23 @@ __global__ __launch_bounds__(256) void linattn_reduce_pair_kernel(const float* _
   }
 }
 
-// apply for both streams in one launch (C = 256, D = 32, one segment per stream)
-constexpr int kApplyChunk = 8;
-__global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __restrict__ qkv, int ld,
+// apply for both streams in one launch (C = 256, D = 32, one segment per stream) on the fp32 MFMA:
+//   msg[t][h*32 + v] = (sum_d Q[t][h*32+d] KV_h[d][v]) / (sum_d Q[t][h*32+d] Ksum_h[d] + eps) * S
+// Block = 32 tokens of one stream x 8 waves, wave = head.  The Q tile is staged in LDS with coalesced
+// 16-byte loads (row stride 258 floats: the 64 lanes of an A-operand read hit 64 different banks);
+// num = mfma_32x32x2(A = Q tile, B = KV_h) over 16 steps (the fp32 MFMA accumulates k in ascending order with one
+// rounding per product-add, i.e. the chain of a scalar fmaf loop over d); the normaliser is one scalar chain per
+// (token, head), shared by the 32 columns of the head through LDS.
+constexpr int kApplyChunk = 32;
+__global__ __launch_bounds__(512) void linattn_apply_pair_kernel(const float* __restrict__ qkv, int ld,
                                                                 const float* __restrict__ kv,
                                                                 const float* __restrict__ ks, int cross,
                                                                 float* __restrict__ out, int ldo, int len0, int len1,
                                                                 int chunks0, float eps) {
-  constexpr int C = 256, D = 32, TB = 8, CHUNK = kApplyChunk;   // one LDS stage per block; occupancy hides the latency
-  __shared__ __attribute__((aligned(16))) float qsh[TB][C];
+  constexpr int C = 256, D = 32, H = 8, CHUNK = kApplyChunk, QS = 258;
+  __shared__ __attribute__((aligned(16))) float qsh[CHUNK * QS];
+  __shared__ float z_sh[H][CHUNK];
   const int t = threadIdx.x;
-  const int h = t / D, v = t % D;
   const int stream = blockIdx.x >= chunks0 ? 1 : 0;
   const int cidx = stream ? blockIdx.x - chunks0 : blockIdx.x;
   const int seg_len = stream ? len1 : len0;
@@ -436,44 +442,44 @@ __global__ __launch_bounds__(256) void linattn_apply_pair_kernel(const float* __
   const int src = cross ? 1 - stream : stream;          // quirk q6: both streams use pre-update K,V
   const float src_len = (float)(src ? len1 : len0);
   const int s_begin = cidx * CHUNK;
-  const int s_end = min(seg_len, s_begin + CHUNK);
-  float kvr[D], ksr[D];
   const float* kvp = kv + (size_t)src * (C * D);
   const float* ksp = ks + (size_t)src * C;
+  const int lane = t & 63, h = t >> 6;                  // wave = head
+  const int half = lane >> 5, l31 = lane & 31;
+  float bk[16];                                          // B operand: KV_h[d = 2 i + half][v = l31], in flight during the staging
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    kvr[d] = kvp[(h * D + d) * D + v];
-    ksr[d] = ksp[h * D + d];
+  for (int i = 0; i < 16; ++i) bk[i] = kvp[(h * D + 2 * i + half) * D + l31];
+#pragma unroll
+  for (int i = 0; i < CHUNK * (C / 4) / 512; ++i) {
+    const int e = t + i * 512;
+    const int r = e / (C / 4), c4 = e - r * (C / 4);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s_begin + r < seg_len) q = *reinterpret_cast<const float4*>(qkv + (size_t)(base + s_begin + r) * ld + c4 * 4);
+    float2* dst = reinterpret_cast<float2*>(qsh + r * QS + c4 * 4);
+    dst[0] = make_float2(q.x, q.y);
+    dst[1] = make_float2(q.z, q.w);
   }
-  for (int s0 = s_begin; s0 < s_end; s0 += TB) {
+  __syncthreads();
+  if (t < H * CHUNK) {   // the normaliser of (token, head): one thread each, a sequential fmaf chain over d
+    const int tok = t & (CHUNK - 1), hh = t / CHUNK;
+    const float* q = qsh + tok * QS + hh * D;
+    const float* k = ksp + hh * D;
+    float den = 0.f;
 #pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      const int s = s0 + j;
-      qsh[j][t] = s < s_end ? qkv[(size_t)(base + s) * ld + t] : 0.f;
-    }
-    __syncthreads();
+    for (int d = 0; d < D; ++d) den = fmaf(q[d], k[d], den);
+    z_sh[hh][tok] = 1.0f / (den + eps);
+  }
+  f32x16_t num;
 #pragma unroll
-    for (int j = 0; j < TB; ++j) {
-      const int s = s0 + j;
-      if (s >= s_end) break;
-      const float4* qr = reinterpret_cast<const float4*>(&qsh[j][h * D]);
-      float num = 0.f, den = 0.f;
+  for (int r = 0; r < 16; ++r) num[r] = 0.f;
 #pragma unroll
-      for (int d4 = 0; d4 < D / 4; ++d4) {
-        const float4 q4 = qr[d4];
-        num = fmaf(q4.x, kvr[d4 * 4 + 0], num);
-        den = fmaf(q4.x, ksr[d4 * 4 + 0], den);
-        num = fmaf(q4.y, kvr[d4 * 4 + 1], num);
-        den = fmaf(q4.y, ksr[d4 * 4 + 1], den);
-        num = fmaf(q4.z, kvr[d4 * 4 + 2], num);
-        den = fmaf(q4.z, ksr[d4 * 4 + 2], den);
-        num = fmaf(q4.w, kvr[d4 * 4 + 3], num);
-        den = fmaf(q4.w, ksr[d4 * 4 + 3], den);
-      }
-      const float z = 1.0f / (den + eps);
-      out[(size_t)(base + s) * ldo + t] = (num * z) * src_len;
-    }
-    __syncthreads();
+  for (int i = 0; i < 16; ++i) num = __builtin_amdgcn_mfma_f32_32x32x2f32(qsh[l31 * QS + h * D + 2 * i + half], bk[i], num, 0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int tok = s_begin + row;
+    if (tok < seg_len) out[(size_t)(base + tok) * ldo + h * D + l31] = (num[r] * z_sh[h][row]) * src_len;
   }
 }
 
@@ -595,7 +601,7 @@ int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const floa
                            int len0, int len1, float eps, hipStream_t stream) {
   const int c0 = opp_cdiv(len0, kApplyChunk), c1 = opp_cdiv(len1, kApplyChunk);
   OppProfScope prof(OPP_PROF_LINATTN_APPLY, stream, (double)(len0 + len1) * 256.0 * 4.0 * 2.0);   // Q read + message written
-  hipLaunchKernelGGL(linattn_apply_pair_kernel, dim3(c0 + c1), dim3(256), 0, stream, qkv, ld, kv, ks, cross, out, ldo, len0, len1,
+  hipLaunchKernelGGL(linattn_apply_pair_kernel, dim3(c0 + c1), dim3(512), 0, stream, qkv, ld, kv, ks, cross, out, ldo, len0, len1,
                      c0, eps);
   OPP_CHECK_LAUNCH("linattn_apply_pair_kernel");
   return OPP_OK;
