@@ -199,6 +199,15 @@ int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, 
                          int cout_pad, int cin_pad, float* out, void* stream);
 /* floats per packed weight row of a (cin, ks) convolution */
 int opp_conv_packed_k(int cin, int ks);
+/* LinearAttention (loftr_module/linear_attention.py:29-61) of the two token streams of one encoder layer, as the
+ * transformer runs it.  qkv [n_seg * (len0 + len1)][3 C]: per row phi(Q) | phi(K) | V / S (phi = elu + 1, S = the
+ * row's own stream length; the QKV GEMM epilogue produces exactly this), the n_seg segments of stream 0 (len0 rows
+ * each) first, then those of stream 1 (len1 rows each).  msg [same rows][C] = phi(Q) (sum_s phi(K_s)^T V_s / S)
+ * / (phi(Q) . sum_s phi(K_s) + 1e-6) * S_src; cross = 0: every stream attends to itself, 1: to the other stream's
+ * K, V of the same segment.  Supported: (C, nhead) = (256, 8) and (128, 8). */
+size_t opp_linear_attention_workspace_bytes(int n_seg, int len0, int len1, int C, int nhead);
+int opp_linear_attention(const float* qkv, int n_seg, int len0, int len1, int C, int nhead, int cross,
+                         float* msg, void* workspace, size_t workspace_bytes, void* stream);
 /* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  prec as above (1: W pre-split by opp_pack_h2,
  * 2: by opp_pack_b3). */
 int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,

@@ -80,6 +80,8 @@ SIGNATURES = {
     "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_conv_packed_k": (c_int, [c_int, c_int]),
+    "opp_linear_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "opp_linear_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -833,6 +833,41 @@ struct TrBufs {
   float *qkv, *msg, *mrg, *hid, *kv, *ks, *scratch;
 };
 
+// scratch floats of the linear attention of (n_seg x (len0 + len1)) tokens: chunk partials of the KV reduction
+size_t linattn_scratch_floats(int C, int D, int n_seg, int len0, int len1) {
+  const int ch = opp_linattn_chunks(len0) > opp_linattn_chunks(len1) ? opp_linattn_chunks(len0) : opp_linattn_chunks(len1);
+  size_t sc = (size_t)n_seg * ch * (C * D + C);
+  if (n_seg == 1 && C == 256) {
+    const size_t pair = opp_linattn_pair_scratch_floats(len0, len1);
+    sc = pair > sc ? pair : sc;
+  }
+  return sc;
+}
+
+// LinearAttention (linear_attention.py:29-61) of both streams of one encoder layer.  qkv [n_seg * (len0 + len1)][3 C]:
+// phi(Q) | phi(K) | V / S per row (stream-0 segments first); msg [same rows][C].  kv [2][n_seg][C * D], ks [2][n_seg][C].
+// self: each stream attends to itself; cross: to the other stream's (pre-update) K, V (quirk q6).
+int run_linattn(const float* qkv, int C, int D, int n_seg, int len0, int len1, bool cross, float* kv, float* ks, float* scratch,
+                float* msg, float eps, hipStream_t s) {
+  const int T0 = n_seg * len0;
+  float* kv0 = kv;
+  float* kv1 = kv + (size_t)n_seg * C * D;
+  float* ks0 = ks;
+  float* ks1 = ks + (size_t)n_seg * C;
+  const float* q0 = qkv;
+  const float* q1 = qkv + (size_t)T0 * 3 * C;
+  if (n_seg == 1 && C == 256 && D == 32) {   // coarse level: MFMA KV reduction and apply, both streams per launch
+    OPP_TRY(opp_linattn_kv_pair(qkv, 3 * C, len0, len1, kv0, ks0, scratch, s));
+    return opp_linattn_apply_pair(qkv, 3 * C, kv0, ks0, cross ? 1 : 0, msg, C, len0, len1, eps, s);
+  }
+  if (opp_linattn_small_ok(len0, len1, C, D))   // fine level: one launch, KV never leaves the CU
+    return opp_linattn_small_pair(qkv, 3 * C, n_seg, len0, len1, cross ? 1 : 0, msg, C, C, D, eps, s);
+  OPP_TRY(opp_linattn_kv(q0 + C, q0 + 2 * C, 3 * C, n_seg, len0, C, D, kv0, ks0, scratch, s));
+  OPP_TRY(opp_linattn_kv(q1 + C, q1 + 2 * C, 3 * C, n_seg, len1, C, D, kv1, ks1, scratch, s));
+  OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps, s));
+  return opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps, s);
+}
+
 size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, TrBufs& b) {
   const size_t T = (size_t)n_seg * (len0 + len1);
   b.qkv = a.f(T * 3 * C);
@@ -841,13 +876,7 @@ size_t plan_transformer(int C, int D, int n_seg, int len0, int len1, Arena& a, T
   b.hid = a.f(T * 2 * C);
   b.kv = a.f((size_t)2 * n_seg * C * D);
   b.ks = a.f((size_t)2 * n_seg * C);
-  const int ch = opp_linattn_chunks(len0) > opp_linattn_chunks(len1) ? opp_linattn_chunks(len0) : opp_linattn_chunks(len1);
-  size_t sc = (size_t)n_seg * ch * (C * D + C);
-  if (n_seg == 1 && C == 256) {
-    const size_t pair = opp_linattn_pair_scratch_floats(len0, len1);
-    sc = pair > sc ? pair : sc;
-  }
-  b.scratch = a.f(sc);
+  b.scratch = a.f(linattn_scratch_floats(C, D, n_seg, len0, len1));
   return a.off;
 }
 
@@ -902,10 +931,6 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     opp_set_error("transformer: workspace too small");
     return OPP_ERR_WORKSPACE;
   }
-  float* kv0 = b.kv;
-  float* kv1 = b.kv + (size_t)n_seg * C * D;
-  float* ks0 = b.ks;
-  float* ks1 = b.ks + (size_t)n_seg * C;
   const float eps_attn = 1e-6f, eps_ln = 1e-5f;
   static const int fuse_env = getenv("OPP_FUSE_LN") ? atoi(getenv("OPP_FUSE_LN")) : 1;   // tuning knob
   const bool fuse_ln = fuse_env && (C == 256 || C == 128);
@@ -938,20 +963,7 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.h2_inv = (h2 == OPP_PREC_FP16X2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
     }
-    const float* q0 = b.qkv;
-    const float* q1 = b.qkv + (size_t)T0 * 3 * C;
-    if (n_seg == 1 && C == 256 && D == 32) {   // coarse level: MFMA KV reduction, both streams per launch
-      OPP_TRY(opp_linattn_kv_pair(b.qkv, 3 * C, len0, len1, kv0, ks0, b.scratch, s));
-      OPP_TRY(opp_linattn_apply_pair(b.qkv, 3 * C, kv0, ks0, cross ? 1 : 0, b.msg, C, len0, len1, eps_attn, s));
-    } else if (opp_linattn_small_ok(len0, len1, C, D)) {   // fine level: one launch, KV never leaves the CU
-      OPP_TRY(opp_linattn_small_pair(b.qkv, 3 * C, n_seg, len0, len1, cross ? 1 : 0, b.msg, C, C, D, eps_attn, s));
-    } else {
-    OPP_TRY(opp_linattn_kv(q0 + C, q0 + 2 * C, 3 * C, n_seg, len0, C, D, kv0, ks0, b.scratch, s));
-    OPP_TRY(opp_linattn_kv(q1 + C, q1 + 2 * C, 3 * C, n_seg, len1, C, D, kv1, ks1, b.scratch, s));
-    // self: each stream attends to itself; cross: to the other stream's (pre-update) K,V (quirk q6)
-    OPP_TRY(opp_linattn_apply(q0, 3 * C, cross ? kv1 : kv0, cross ? ks1 : ks0, b.msg, C, n_seg, len0, cross ? len1 : len0, C, D, eps_attn, s));
-    OPP_TRY(opp_linattn_apply(q1, 3 * C, cross ? kv0 : kv1, cross ? ks0 : ks1, b.msg + (size_t)T0 * C, C, n_seg, len1, cross ? len0 : len1, C, D, eps_attn, s));
-    }
+    OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, len1, cross, b.kv, b.ks, b.scratch, b.msg, eps_attn, s));
     if (fuse_ln) {
       // merge -> norm1 and mlp.2 -> norm2 -> +x in the GEMM epilogues (64-row tiles spanning the whole row)
       LnArgs n1, n2;
@@ -992,6 +1004,36 @@ extern "C" int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* b
   OPP_CHECK_ARG(ctx && ctx->packed && kpts && bank_c && tokens3d && ws && n > 0, "encode_points: bad argument");
   Arena a(ws, ws_bytes);
   return encode_points_impl(ctx, kpts, bank_c, n, tokens3d, a, (hipStream_t)stream);
+}
+
+namespace {
+size_t plan_linear_attention(int C, int D, int n_seg, int len0, int len1, Arena& a, float** kv, float** ks, float** scratch) {
+  *kv = a.f((size_t)2 * n_seg * C * D);
+  *ks = a.f((size_t)2 * n_seg * C);
+  *scratch = a.f(linattn_scratch_floats(C, D, n_seg, len0, len1));
+  return a.off;
+}
+}  // namespace
+
+extern "C" size_t opp_linear_attention_workspace_bytes(int n_seg, int len0, int len1, int C, int nhead) {
+  if (n_seg <= 0 || nhead <= 0 || C % nhead) return 0;
+  Arena a(nullptr, 0);
+  float *kv, *ks, *sc;
+  return opp_align(plan_linear_attention(C, C / nhead, n_seg, len0, len1, a, &kv, &ks, &sc)) + 256;
+}
+
+extern "C" int opp_linear_attention(const float* qkv, int n_seg, int len0, int len1, int C, int nhead, int cross, float* msg,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(qkv && msg && ws, "linear_attention: null argument");
+  OPP_CHECK_ARG(n_seg > 0 && len0 > 0 && len1 > 0 && nhead > 0 && C % nhead == 0, "linear_attention: bad shape");
+  Arena a(ws, ws_bytes);
+  float *kv, *ks, *sc;
+  plan_linear_attention(C, C / nhead, n_seg, len0, len1, a, &kv, &ks, &sc);
+  if (!a.ok) {
+    opp_set_error("linear_attention: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  return run_linattn(qkv, C, C / nhead, n_seg, len0, len1, cross != 0, kv, ks, sc, msg, 1e-6f, (hipStream_t)stream);
 }
 
 extern "C" size_t opp_transformer_workspace_bytes(const opp_ctx* ctx, int which, int n_seg, int len0, int len1) {

@@ -138,6 +138,18 @@ def layer_norm(x, g, b, res=None):
 PRECISIONS = ("bf16x3", "fp32", "fp16x2", "fp16x2_all")
 
 
+def linear_attention(qkv, n_seg, len0, len1, C, nhead, cross):
+    """qkv [n_seg*(len0+len1), 3C] (phi(Q) | phi(K) | V/S) -> message [same rows, C] (opp_linear_attention)."""
+    lib = _lib.load()
+    q = qkv.cuda().contiguous()
+    msg = torch.full((q.shape[0], C), float("nan"), device="cuda")
+    ws = torch.empty(lib.opp_linear_attention_workspace_bytes(n_seg, len0, len1, C, nhead), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_linear_attention(q.data_ptr(), n_seg, len0, len1, C, nhead, cross, msg.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), _s()), "linear_attention")
+    torch.cuda.synchronize()
+    return msg.cpu()
+
+
 def make_model(cfg, sd, precision=None):
     m = OnePosePlus_model(cfg).eval()
     m.load_state_dict(sd, strict=True)

@@ -329,3 +329,66 @@ def test_results_do_not_depend_on_the_tile_shape(h2):
             low = torch.randn(1, cout, Ho // 2, Wo // 2, generator=g)
             outs = [ops.conv2d(x, w, None, None, 1, low, 2, 0, c, h2=h2)[0] for c in cfgs]
             assert all(torch.equal(outs[0], o) for o in outs[1:]), "bilinear residual"
+
+
+# ---- LinearAttention on its own (loftr_module/linear_attention.py:29-61) --------------------------------------------
+LINATTN_CASES = [
+    # n_seg, len0, len1, C, nhead            code path
+    (1, 4096, 5000, 256, 8),               # coarse level: MFMA gather + MFMA apply, both streams per launch
+    (1, 300, 77, 256, 8),                  # ragged chunk tails
+    (1, 33, 1, 256, 8),
+    (37, 25, 1, 128, 8),                   # fine level: one workgroup per match
+    (5, 9, 23, 128, 8),
+    (3, 100, 40, 128, 8),                  # generic path (chunk partials + fixed-order reduction)
+    (2, 640, 300, 256, 8),                 # B > 1 at the coarse level
+]
+
+
+def _linattn_reference(qkv, n_seg, len0, len1, C, nhead, cross):
+    """fp64 restatement of LinearAttention.forward on already-activated inputs: Q = phi(q), K = phi(k), values = v / S;
+    message = Q (K^T values) / (Q . sum K + eps) * S_src per head."""
+    D = C // nhead
+    q = qkv.double()
+    T0 = n_seg * len0
+    streams = [q[:T0].view(n_seg, len0, 3, nhead, D), q[T0:].view(n_seg, len1, 3, nhead, D)]
+    out = []
+    for st in (0, 1):
+        src = streams[1 - st] if cross else streams[st]
+        Q, K, V = streams[st][:, :, 0], src[:, :, 1], src[:, :, 2]
+        KV = torch.einsum("nshd,nshv->nhdv", K, V)
+        Z = 1.0 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + 1e-6)
+        out.append((torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * src.shape[1]).reshape(-1, C))
+    return torch.cat(out, 0)
+
+
+@pytest.mark.parametrize("n_seg,len0,len1,C,nhead", LINATTN_CASES)
+@pytest.mark.parametrize("cross", [0, 1])
+def test_linear_attention_vs_fp64(n_seg, len0, len1, C, nhead, cross):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(n_seg * 131 + len0 + 7 * len1 + cross)
+    T0, T1 = n_seg * len0, n_seg * len1
+    raw = torch.randn(T0 + T1, 3 * C, generator=g)
+    qkv = raw.clone()
+    qkv[:, :2 * C] = F.elu(raw[:, :2 * C]) + 1.0                      # phi (linear_attention.py:5-6)
+    qkv[:T0, 2 * C:] = raw[:T0, 2 * C:] / len0                        # values / S (linear_attention.py:55-56)
+    qkv[T0:, 2 * C:] = raw[T0:, 2 * C:] / len1
+    ref = _linattn_reference(qkv, n_seg, len0, len1, C, nhead, cross)
+    got = ops.linear_attention(qkv, n_seg, len0, len1, C, nhead, cross)
+    assert torch.isfinite(got).all()
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    # zeroed K / V rows (what query_image_mask does to masked image tokens) contribute nothing
+    if len0 >= 8:
+        masked = qkv.clone()
+        drop = torch.arange(0, len0, 3)
+        masked.view(-1, 3 * C)[drop, C:] = 0.0
+        dense = masked[:T0].view(n_seg, len0, 3 * C)
+        keep = torch.ones(len0, dtype=torch.bool)
+        keep[drop] = False
+        if n_seg == 1 and cross:   # stream 1 attends to the kept rows of stream 0 only
+            got_m = ops.linear_attention(masked, n_seg, len0, len1, C, nhead, cross)
+            sub = torch.cat([dense[:, keep].reshape(-1, 3 * C), masked[T0:]], 0)
+            ref_m = _linattn_reference(sub, n_seg, int(keep.sum()), len1, C, nhead, cross)[-T1:]
+            # the source length factor stays len0 (the reference multiplies by the padded length, linear_attention.py:59)
+            ref_m = ref_m * (len0 / float(keep.sum()))
+            assert (got_m[-T1:].double() - ref_m).abs().max().item() <= 2e-5 * max(1.0, ref_m.abs().max().item())
