@@ -69,21 +69,24 @@ __global__ void pack_stem_kernel(const float* __restrict__ w, const float* __res
 // col[(b*Ho+oy)*Wo+ox][k] = img[b][2*oy+ky-3][2*ox+kx-3], k = ky*7+kx < 49, else 0.
 __global__ void stem_im2col_kernel(const float* __restrict__ img, int B, int H, int W, int Ho, int Wo,
                                    float* __restrict__ col) {
-  const size_t total = (size_t)B * Ho * Wo * 64;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i & 63);
-    const size_t p = i >> 6;
-    const int ox = (int)(p % Wo);
-    const size_t t = p / Wo;
-    const int oy = (int)(t % Ho);
-    const int b = (int)(t / Ho);
-    float v = 0.f;
-    if (k < 49) {
+  // one 16-byte store per lane (4 consecutive k), 32-bit index arithmetic (B * Ho * Wo * 16 < 2^31 checked by the launcher)
+  const unsigned total = (unsigned)(B * Ho * Wo) * 16u;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int k0 = (int)(i & 15u) * 4;
+    const unsigned p = i >> 4;
+    const int ox = (int)(p % (unsigned)Wo);
+    const unsigned t = p / (unsigned)Wo;
+    const int oy = (int)(t % (unsigned)Ho);
+    const int b = (int)(t / (unsigned)Ho);
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
       const int ky = k / 7, kx = k - ky * 7;
       const int iy = 2 * oy + ky - 3, ix = 2 * ox + kx - 3;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[((size_t)b * H + iy) * W + ix];
+      v[e] = (k < 49 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? img[((size_t)b * H + iy) * W + ix] : 0.f;
     }
-    col[i] = v;
+    reinterpret_cast<float4*>(col)[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -214,7 +217,8 @@ int opp_pack_stem(const float* w, const float* scale, int cout, float* out, hipS
 
 int opp_stem_im2col(const float* img, int B, int H, int W, float* col, hipStream_t stream) {
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-  const size_t total = (size_t)B * Ho * Wo * 64;
+  OPP_CHECK_ARG((size_t)B * Ho * Wo * 16 < (1ull << 31), "stem im2col: image batch too large for 32-bit indexing");
+  const size_t total = (size_t)B * Ho * Wo * 16;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks), dim3(256), 0, stream, img, B, H, W, Ho, Wo, col);
   OPP_CHECK_LAUNCH("stem_im2col_kernel");
