@@ -423,8 +423,9 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
 def train_leg(torch, dev, precision, nsteps=2):
     """One training step at the per-GPU shape of BASELINE configs[4] (B = 4, 512x512, N = 7000 points padded as the
     reference's dataset does, train.yaml:185,194): train()-mode forward on the HIP path (BatchNorm batch statistics,
-    training branch of get_coarse_match, fine level on the padded matches), a focal-style scalar on conf_matrix +
-    expec_f, backward (PyTorch ops re-evaluating the graph, onepose_plus_plus_amd/train_autograd.py) and an SGD update."""
+    training branch of get_coarse_match, fine level on the padded matches), `fine_supervision` + `Loss` of this package
+    (focal loss over the 115 M-entry confidence matrix and its gradient in HIP), model backward (PyTorch ops
+    re-evaluating the graph, onepose_plus_plus_amd/train_autograd.py) and an AdamW update."""
     from onepose_plus_plus_amd import OnePosePlus_model, default_config
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
     B, N, hw = 4, 7000, (512, 512)
@@ -439,21 +440,44 @@ def train_leg(torch, dev, precision, nsteps=2):
     for b in range(B):
         gt[b, torch.randperm(N, generator=g)[:1500], torch.randperm(4096, generator=g)[:1500]] = 1
     base["conf_matrix_gt"] = gt.to(dev)
-    opt = torch.optim.SGD(model.parameters(), lr=1e-5)
+    from onepose_plus_plus_amd.losses import Loss, fine_supervision
+    loc = torch.full((B, N, 4096, 2), -50.0, device=dev)                      # fine_location_matrix_gt as the loader pads it
+    pos = torch.nonzero(base["conf_matrix_gt"] == 1)
+    cell = torch.stack([pos[:, 2] % 64, pos[:, 2] // 64], 1).float() * 8.0
+    loc[pos[:, 0], pos[:, 1], pos[:, 2]] = cell + torch.rand(len(pos), 2, device=dev) * 4.0 - 2.0
+    base["fine_location_matrix_gt"] = loc
+    hparams = {"OnePosePlus": cfg, "loss": {"coarse_type": "focal", "coarse_weight": 1.0, "fine_type": "l2_with_std",
+                                            "fine_weight": 0.81, "focal_alpha": 0.5, "focal_gamma": 2.0, "pos_weight": 1.0,
+                                            "neg_weight": 1.0, "fine_correct_thr": 1.0}}      # train.yaml:129-144
+    loss_mod = Loss(hparams["loss"]).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-6)
 
     def fwd_only():
         d = dict(base)
         with torch.no_grad():
             model(d)
 
-    def full_step():
+    def full_step():                         # PL_OnePosePlus.training_step, lightning_model:54-60, + the optimiser
         d = dict(base)
         model(d)
-        loss = -(torch.log(d["conf_matrix"][d["conf_matrix_gt"] == 1].clamp(1e-6))).mean() + (d["expec_f"][:, :2] ** 2).sum(-1).mean()
+        fine_supervision(d, hparams)
+        loss_mod(d)
         opt.zero_grad(set_to_none=True)
-        loss.backward()
+        d["loss"].backward()
         opt.step()
-        return float(loss.detach())
+        return float(d["loss"].detach())
+
+    def loss_only():
+        d = dict(base)
+        with torch.no_grad():
+            model(d)
+        conf = d["conf_matrix"].detach().requires_grad_(True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        lc = loss_mod.compute_coarse_loss(conf, d["conf_matrix_gt"])
+        lc.backward()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) * 1e3
 
     def timed(fn):
         fn()
@@ -466,10 +490,17 @@ def train_leg(torch, dev, precision, nsteps=2):
 
     fwd_ms, _ = timed(fwd_only)
     step_ms, loss = timed(full_step)
-    return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, 7000 points, train() mode, single stream",
+    loss_only()
+    focal_ms = min(loss_only() for _ in range(3))
+    n_conf = B * N * 4096
+    return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, 7000 points, train() mode, single stream; "
+                        "step = model(batch), fine_supervision, Loss (focal + l2_with_std, train.yaml:129-144), backward, AdamW",
             "forward_ms": round(fwd_ms, 2), "forward_samples_per_s": round(B / fwd_ms * 1e3, 1),
             "step_ms": round(step_ms, 1), "step_samples_per_s": round(B / step_ms * 1e3, 2), "loss": round(loss, 5),
-            "note": "forward = hand-written HIP path; backward = PyTorch ops on the device (not hand-written yet)"}
+            "focal_loss_fwd_bwd_ms": round(focal_ms, 3),
+            "focal_loss_alg_gbs": round(n_conf * 16.0 / (focal_ms * 1e-3) / 1e9, 1),
+            "note": "forward, focal loss and its gradient = hand-written HIP; model backward = PyTorch ops on the device "
+                    "(not hand-written yet)"}
 
 
 def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):

@@ -182,6 +182,20 @@ int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* ban
              const float* mkpts_c, float base_scale, const float* query_scale, int run_transformer,
              float* expec_f, float* mkpts_f, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training step: coarse focal loss (Loss.compute_coarse_loss, src/lightning_model/losses.py:18-55) -------------
+ * conf [n] fp32 (the B x N x L confidence matrix, 16-byte aligned), conf_gt [n] int16 (0 / 1; other values are ignored
+ * like the reference's `== 1` / `== 0` masks), weight [n] or NULL.
+ * forward: sums[4] (device, fp64) = { sum of the positive terms, sum of the negative terms, #positives, #negatives };
+ *   term_pos = -alpha (1 - c)^gamma log c, term_neg = -(1 - alpha) c^gamma log(1 - c), c = clamp(conf, 1e-6, 1 - 1e-6);
+ *   the caller forms pos_weight * mean_pos + neg_weight * mean_neg (losses.py:44-53) from them without a host sync.
+ * backward: grad_conf [n] = d loss / d conf given scales[2] (device) = { g * pos_weight / #pos, g * neg_weight / #neg },
+ *   g the incoming gradient of the scalar loss; zero where the clamp saturates. */
+size_t opp_focal_loss_workspace_bytes(size_t n);
+int opp_focal_loss_forward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
+                           float gamma, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int opp_focal_loss_backward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
+                            float gamma, const float* scales, float* grad_conf, void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

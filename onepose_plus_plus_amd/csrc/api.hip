@@ -1253,6 +1253,21 @@ extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout
   return opp_pack_conv(w, scale, cout, cin, ks, cout_pad, cin_pad, out, (hipStream_t)stream);
 }
 
+// ----------------------------------------------------------------------------------------
+// training loss
+// ----------------------------------------------------------------------------------------
+extern "C" size_t opp_focal_loss_workspace_bytes(size_t n) { return opp_focal_loss_ws_bytes(n) + 256; }
+
+extern "C" int opp_focal_loss_forward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
+                                      float gamma, double* sums, void* ws, size_t ws_bytes, void* stream) {
+  return opp_focal_loss_fwd(conf, conf_gt, weight, n, alpha, gamma, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int opp_focal_loss_backward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
+                                       float gamma, const float* scales, float* grad_conf, void* stream) {
+  return opp_focal_loss_bwd(conf, conf_gt, weight, n, alpha, gamma, scales, grad_conf, (hipStream_t)stream);
+}
+
 extern "C" int opp_conv_packed_k(int cin, int ks) { return opp_conv_k(cin, ks); }
 
 extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {

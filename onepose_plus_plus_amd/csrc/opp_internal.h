@@ -14,6 +14,8 @@ enum {
   OPP_PROF_LINATTN_SMALL = 1004,   // linattn_small_pair_kernel: fine-level attention, one workgroup per match
   OPP_PROF_FINE_GATHER = 1005,     // fine_gather_kernel
   OPP_PROF_FINE_HEAD = 1006,       // fine_head_kernel
+  OPP_PROF_FOCAL_FWD = 1007,       // focal_fwd_kernel: coarse focal loss over the B x N x L confidence matrix
+  OPP_PROF_FOCAL_BWD = 1008,       // focal_bwd_kernel: its gradient
 };
 inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
 struct OppProfScope {
@@ -38,6 +40,12 @@ int opp_linattn_apply(const float* q, int ldq, const float* kv, const float* ks,
 size_t opp_linattn_pair_scratch_floats(int len0, int len1);
 int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
                         hipStream_t stream);
+// coarse focal loss of the training step (loss.hip)
+size_t opp_focal_loss_ws_bytes(size_t n);
+int opp_focal_loss_fwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma, double* sums,
+                       void* ws, size_t ws_bytes, hipStream_t stream);
+int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma,
+                       const float* scales, float* grad, hipStream_t stream);
 // many short segment pairs (fine level: 25 window tokens + 1 point token per match): KV, Ksum and the apply of both
 // streams of one segment in one workgroup
 bool opp_linattn_small_ok(int len0, int len1, int C, int D);

@@ -11,7 +11,9 @@
         (src/lightning_model/OnePosePlus_lightning_model.py:8 via src/models/OnePosePlus/__init__.py:1)
 and, with `pnp=True`, routes `src.utils.metric_utils.ransac_PnP` (called by `compute_query_pose_errors`,
 metric_utils.py:262-270, i.e. by every caller of the matcher: inference worker, demo, validation step) to the
-on-device `onepose_plus_plus_amd.pose.ransac_PnP`, which keeps the reference's signature and return tuple.
+on-device `onepose_plus_plus_amd.pose.ransac_PnP`, which keeps the reference's signature and return tuple; with
+`loss=True` the training step's `Loss` (src/lightning_model/losses.py) and `fine_supervision`
+(src/models/OnePosePlus/utils/fine_supervision.py) resolve to `onepose_plus_plus_amd.losses`.
 
 If the reference modules were imported already their attributes are patched in place; otherwise light-weight module
 objects are registered under those names, so the reference's own model files (and their kornia / timm imports) are
@@ -26,6 +28,13 @@ from .model import OnePosePlus_model
 _MODEL_PATHS = ("src.models.OnePosePlus.OnePosePlusModel", "src.models.OnePosePlus")
 
 
+def _real_dirs(name):
+    """directories of package `name` found on sys.path (empty on a box without the reference checkout)"""
+    import os
+    rel = os.path.join(*name.split("."))
+    return [os.path.join(p, rel) for p in sys.path if p and os.path.isdir(os.path.join(p, rel))]
+
+
 def _ensure_package(name):
     """registers empty parent packages (src, src.models) only when the real ones cannot be imported"""
     if name in sys.modules:
@@ -34,7 +43,7 @@ def _ensure_package(name):
         return importlib.import_module(name)
     except Exception:
         mod = types.ModuleType(name)
-        mod.__path__ = []
+        mod.__path__ = _real_dirs(name)       # sub-modules that do import cleanly still come from the checkout
         sys.modules[name] = mod
         parent, _, leaf = name.rpartition(".")
         if parent:
@@ -42,7 +51,21 @@ def _ensure_package(name):
         return mod
 
 
-def install(pnp=True):
+def _patch_attr(path, name, obj, done):
+    """sets `path.name = obj` on the imported module, or on a light-weight stand-in registered under that path when the
+    reference file was not imported yet (so that a later `from path import name` resolves to `obj`)"""
+    mod = sys.modules.get(path)
+    if mod is None:
+        parent, _, leaf = path.rpartition(".")
+        pkg = _ensure_package(parent)
+        mod = types.ModuleType(path)
+        sys.modules[path] = mod
+        setattr(pkg, leaf, mod)
+    setattr(mod, name, obj)
+    done[path] = name
+
+
+def install(pnp=True, loss=True):
     """-> dict of what was patched (for logging / tests)"""
     done = {}
     for path in _MODEL_PATHS:
@@ -52,7 +75,9 @@ def install(pnp=True):
             pkg = _ensure_package(parent)
             mod = types.ModuleType(path)
             if path == "src.models.OnePosePlus":
-                mod.__path__ = []
+                # a stand-in for the package (its real __init__ would load the reference model and kornia / timm); the
+                # reference's other sub-packages (optimizers, utils, ...) stay importable from the checkout, if there is one
+                mod.__path__ = _real_dirs(path)
             sys.modules[path] = mod
             setattr(pkg, leaf, mod)
         mod.OnePosePlus_model = OnePosePlus_model
@@ -67,4 +92,14 @@ def install(pnp=True):
             done["src.utils.metric_utils"] = "ransac_PnP"
         except Exception as e:      # the reference (or one of its dependencies) is not importable here
             done["src.utils.metric_utils"] = "not patched: %s" % (e,)
+    if loss:
+        # training step (src/lightning_model/OnePosePlus_lightning_model.py:9,14): `fine_supervision(batch, hparams)` and
+        # `Loss(hparams["loss"])` -> the module's own (the focal loss over the B x N x L matrix runs in libopp_hip.so)
+        from .losses import Loss, fine_supervision
+        _patch_attr("src.lightning_model.losses", "Loss", Loss, done)
+        _patch_attr("src.models.OnePosePlus.utils.fine_supervision", "fine_supervision", fine_supervision, done)
+        lm = sys.modules.get("src.lightning_model.OnePosePlus_lightning_model")
+        if lm is not None:          # imported before install(): its module-level names were bound already
+            lm.Loss, lm.fine_supervision = Loss, fine_supervision
+            done["src.lightning_model.OnePosePlus_lightning_model"] = "Loss, fine_supervision"
     return done

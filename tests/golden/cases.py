@@ -56,3 +56,13 @@ TRAIN_CASES = {
     "train_b2_128x128_n300_sub": ((128, 128), 300, 0.0, 0, [1, 5], 60, 0.05, 20),     # predictions sub-sampled (randint)
     "train_b4_64x96_n150": ((64, 96), 150, 0.0, 7, [2, 3, 4, 9], 30, 0.3, 10),        # B = 4 like train.yaml:185
 }
+
+# training-step callers (Loss, fine_supervision): name -> (B, N, hw_c, n_pos per sample, M match rows, seed, masked, no_inside)
+LOSS_CASES = {
+    "loss_b2_n300": (2, 300, (12, 16), 60, 150, 21, False, False),
+    "loss_b1_n77_nopos": (1, 77, (8, 12), 0, 40, 22, False, False),          # empty positive set: the term is dropped
+    "loss_b2_n128_masked": (2, 128, (8, 8), 30, 64, 23, True, False),        # mask0 / mask1 weights (losses.py:103-109)
+    "loss_b2_n64_no_inside": (2, 64, (8, 8), 20, 32, 24, False, True),       # no gt inside its window: dummy fine term
+}
+LOSS_CONFIG = {"coarse_type": "focal", "coarse_weight": 1.0, "fine_type": "l2_with_std", "fine_weight": 0.81,
+               "focal_alpha": 0.5, "focal_gamma": 2.0, "pos_weight": 1.0, "neg_weight": 1.0, "fine_correct_thr": 1.0}   # train.yaml:129-144

@@ -262,6 +262,46 @@ def gen_bankbuild():
         print(name, "points", len(idxs), "rows", desc.shape[0], avg.dtype)
 
 
+def gen_loss():
+    """The reference's own Loss (src/lightning_model/losses.py) and fine_supervision
+    (src/models/OnePosePlus/utils/fine_supervision.py) on seeded inputs: loss values, expec_f_gt and the gradients of the
+    total loss w.r.t. conf_matrix / expec_f by the reference's autograd.  The two files are loaded by path (their
+    packages import pytorch_lightning / kornia), loguru is stubbed."""
+    import importlib.util
+    import types
+    from tests.helpers import loss_inputs
+    from tests.golden.cases import LOSS_CASES, LOSS_CONFIG
+    if "loguru" not in sys.modules:
+        m = types.ModuleType("loguru")
+        m.logger = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, error=lambda *a, **k: None)
+        sys.modules["loguru"] = m
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join("/root/reference", path))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    L = load("src/lightning_model/losses.py", "ref_losses")
+    FS = load("src/models/OnePosePlus/utils/fine_supervision.py", "ref_fine_supervision")
+    for name in LOSS_CASES:
+        data, hparams = loss_inputs(name)
+        data["conf_matrix"].requires_grad_(True)
+        data["expec_f"].requires_grad_(True)
+        FS.fine_supervision(data, hparams)
+        loss_mod = L.Loss(dict(LOSS_CONFIG))
+        loss_mod.train()
+        loss_mod(data)
+        data["loss"].backward()
+        gc = data["conf_matrix"].grad
+        out = {"expec_f_gt": data["expec_f_gt"].numpy(), "loss": data["loss"].detach().numpy(),
+               "loss_c": data["loss_scalars"]["loss_c"].numpy(),
+               "loss_f": data["loss_scalars"]["loss_f"].numpy() if "loss_f" in data["loss_scalars"] else np.array(np.nan),
+               "grad_conf": gc.numpy(), "grad_expec": data["expec_f"].grad.numpy()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, "loss", float(data["loss"]), "loss_c", float(out["loss_c"]), "loss_f", float(out["loss_f"]),
+              "|grad_conf|", float(gc.abs().sum()))
+
+
 def gen_e2e():
     cls = load_reference_model_class()
     for name, (hw, n, thr, wseed, iseed, fine) in E2E_CASES.items():
@@ -356,7 +396,7 @@ if __name__ == "__main__":
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
     steps = {"stages": gen_stage_features, "matcher": gen_matcher, "fine": gen_fine, "e2e": gen_e2e,
              "transformer": gen_transformer, "highconf": gen_highconf, "batch": gen_batch,
-             "train": gen_train, "bankbuild": gen_bankbuild}
+             "train": gen_train, "bankbuild": gen_bankbuild, "loss": gen_loss}
     for k, fn in steps.items():
         if not only or k in only:
             fn()

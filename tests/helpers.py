@@ -320,3 +320,46 @@ def assert_match_outputs(got, gold, tol_conf=TOL_CONF, tol_off=TOL_OFFSET, tol_p
                 err = np.abs(v - gold[k]).max()
                 lim = tol_conf * (50 if k.endswith("sum") else 1)
                 assert err <= lim, (where, k, float(err))
+
+
+def loss_inputs(name):
+    """-> (data dict of CPU tensors for Loss / fine_supervision, experiment-config stub).  conf_matrix carries entries
+    that sit on and beyond the clamp bounds (exact 0 / 1, 1e-8, 1 - 1e-8) on both positive and negative cells."""
+    from tests.golden.cases import LOSS_CASES
+    B, N, hw_c, n_pos, M, seed, masked, no_inside = LOSS_CASES[name]
+    L = hw_c[0] * hw_c[1]
+    g = torch.Generator().manual_seed(seed)
+    conf = torch.rand(B, N, L, generator=g)
+    gt = torch.zeros(B, N, L, dtype=torch.int16)
+    for b in range(B):
+        if n_pos:
+            gt[b, torch.randperm(N, generator=g)[:n_pos], torch.randperm(L, generator=g)[:n_pos]] = 1
+    flat = conf.view(-1)
+    special = torch.tensor([0.0, 1.0, 1e-8, 1.0 - 1e-8, 1e-6, 1.0 - 1e-6, 5e-7])
+    idx_neg = torch.nonzero(gt.view(-1) == 0)[:, 0]
+    flat[idx_neg[torch.randperm(len(idx_neg), generator=g)[:len(special)]]] = special
+    idx_pos = torch.nonzero(gt.view(-1) == 1)[:, 0]
+    if len(idx_pos) >= len(special):
+        flat[idx_pos[torch.randperm(len(idx_pos), generator=g)[:len(special)]]] = special
+    b_ids = torch.randint(0, B, (M,), generator=g).sort().values
+    i_ids = torch.randint(0, N, (M,), generator=g)
+    j_ids = torch.randint(0, L, (M,), generator=g)
+    scale = torch.tensor([[1.0 + 0.25 * (b % 2), 1.0 - 0.125 * (b % 3)] for b in range(B)])
+    cell = torch.stack([j_ids % hw_c[1], j_ids // hw_c[1]], 1) * (8.0 * scale[b_ids][:, [1, 0]])
+    loc = torch.full((B, N, L, 2), -50.0)
+    # ground-truth 2D locations: most inside the 5x5 window of the matched cell, some far outside
+    off = (torch.rand(M, 2, generator=g) - 0.5) * 8.0 * scale[b_ids][:, [1, 0]]
+    far = torch.rand(M, generator=g) < 0.25
+    off[far] = off[far] * 6.0 + 20.0
+    if no_inside:
+        off = off.abs() + 30.0
+    loc[b_ids, i_ids, j_ids] = cell + off
+    expec = torch.cat([torch.rand(M, 2, generator=g) * 2 - 1, torch.rand(M, 1, generator=g) * 1.7 + 0.08], 1)
+    expec[0, 2] = 1e-12                                # below the std clamp (losses.py:79)
+    data = {"conf_matrix": conf, "conf_matrix_gt": gt, "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids,
+            "q_hw_c": torch.Size(hw_c), "query_image_scale": scale, "fine_location_matrix_gt": loc, "expec_f": expec}
+    if masked:
+        data["mask0"] = (torch.rand(B, 1, N, generator=g) > 0.2).float()          # flatten(-2) -> [B, N]
+        data["mask1"] = (torch.rand(B, hw_c[0], hw_c[1], generator=g) > 0.2).float()
+    hparams = {"OnePosePlus": {"loftr_backbone": {"resolution": [8, 2]}, "loftr_fine": {"window_size": 5}}}
+    return data, hparams

@@ -95,6 +95,43 @@ def test_reference_build_model_constructs_the_hip_module(reference_env, tmp_path
     assert fn.__globals__["ransac_PnP"] is pose.ransac_PnP
 
 
+def test_reference_lightning_module_builds_on_the_hip_matcher_and_loss(reference_env):
+    """The reference's own training wrapper (src/lightning_model/OnePosePlus_lightning_model.py, unmodified; a stand-in
+    for pytorch_lightning.LightningModule, which is not installed here): after `dropin.install()` its constructor builds
+    the HIP matcher and the HIP-backed Loss, and `training_step` calls this package's `fine_supervision`."""
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config, dropin, losses
+
+    class _LightningModule(torch.nn.Module):
+        def save_hyperparameters(self):
+            pass                                    # the test sets .hparams itself (Lightning collects the ctor kwargs)
+
+    hp = {"OnePosePlus": default_config(), "trainer": {"n_val_pairs_to_plot": 100, "world_size": 1}, "pretrained_ckpt": None,
+          "loss": {"coarse_type": "focal", "coarse_weight": 1.0, "fine_type": "l2_with_std", "fine_weight": 0.81,
+                   "focal_alpha": 0.5, "focal_gamma": 2.0, "pos_weight": 1.0, "neg_weight": 1.0, "fine_correct_thr": 1.0}}
+    _LightningModule.hparams = hp
+    sys.modules["pytorch_lightning"].LightningModule = _LightningModule
+    _stub("matplotlib")
+    _stub("matplotlib.pyplot")
+    sys.modules["matplotlib"].pyplot = sys.modules["matplotlib.pyplot"]
+    import src.utils                                                        # the reference's package (empty __init__)
+    _stub("src.utils.plot_utils", draw_reprojection_pair=None)              # plotting (matplotlib colour maps at import)
+    done = dropin.install(pnp=True, loss=True)
+    assert done["src.lightning_model.losses"] == "Loss"
+    assert done["src.models.OnePosePlus.utils.fine_supervision"] == "fine_supervision"
+    try:
+        import src.lightning_model.OnePosePlus_lightning_model as LM       # the reference's own file
+    except ImportError as e:                                               # a plotting / comm helper needs more stubs
+        pytest.skip("reference training wrapper not importable here: %s" % e)
+    assert LM.Loss is losses.Loss and LM.fine_supervision is losses.fine_supervision
+    assert LM.OnePosePlus_model is OnePosePlus_model
+    pl_model = LM.PL_OnePosePlus()
+    assert isinstance(pl_model.matcher, OnePosePlus_model) and isinstance(pl_model.loss, losses.Loss)
+    assert pl_model.loss.c_pos_w == 1.0 and pl_model.loss.fine_type == "l2_with_std"
+    # checkpoint keys of the wrapper = `matcher.` + the module's keys (what build_model strips, inference_OnePosePlus.py:32-36)
+    keys = set(pl_model.state_dict())
+    assert {"matcher." + k for k in pl_model.matcher.state_dict()} == keys
+
+
 def test_install_without_reference_modules_registers_both_paths():
     """On a box without the reference checkout the aliases are still importable (what the GPU tests use)."""
     from onepose_plus_plus_amd import OnePosePlus_model, dropin

@@ -168,6 +168,51 @@ def test_training_step_at_baseline_config5_size():
     assert n == 144 and torch.isfinite(loss)
 
 
+def test_training_step_flow_with_hip_loss():
+    """`PL_OnePosePlus.training_step` (lightning_model:54-60) with this package's pieces: model(batch) in train() mode,
+    `fine_supervision(batch, hparams)`, `Loss(hparams['loss'])(batch)`, backward, optimiser step.  The loss equals the
+    oracle's restatement of the reference Loss on the same outputs; every parameter receives a finite gradient."""
+    from oracle import loss_oracle as LO
+    from tests import hip_ops as ops
+    from tests.golden.cases import LOSS_CONFIG
+    from onepose_plus_plus_amd.losses import Loss, fine_supervision
+    name = "train_b4_64x96_n150"
+    cfg, sd, data = H.train_setup(name)
+    model = ops.make_model(cfg, sd)
+    model.train()
+    B, N = data["keypoints3d"].shape[:2]
+    L = data["conf_matrix_gt"].shape[2]
+    g = torch.Generator().manual_seed(77)
+    data["fine_location_matrix_gt"] = torch.full((B, N, L, 2), -50.0)
+    pos = torch.nonzero(data["conf_matrix_gt"] == 1)
+    wc = 96 // 8
+    scale = data["query_image_scale"][pos[:, 0]][:, [1, 0]]
+    cell = torch.stack([pos[:, 2] % wc, pos[:, 2] // wc], 1) * 8.0 * scale
+    data["fine_location_matrix_gt"][pos[:, 0], pos[:, 1], pos[:, 2]] = cell + (torch.rand(len(pos), 2, generator=g) - 0.5) * 6.0 * scale
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    hparams = {"OnePosePlus": cfg, "loss": dict(LOSS_CONFIG)}
+    loss_mod = Loss(hparams["loss"]).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    model(d)
+    fine_supervision(d, hparams)
+    loss_mod(d)
+    assert d["expec_f_gt"].shape == (len(d["b_ids"]), 2)
+    ref = LO.loss_forward({k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()
+                           if k in ("conf_matrix", "conf_matrix_gt", "expec_f", "expec_f_gt")}, LOSS_CONFIG, training=True)
+    assert abs(float(d["loss"].detach()) - float(ref["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+    assert set(d["loss_scalars"]) == {"loss_c", "loss_f", "loss"}
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt.zero_grad()
+    d["loss"].backward()
+    n = 0
+    for k, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        n += 1
+    assert n == 144
+    opt.step()
+    assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())
+
+
 def test_worker_flow_recovers_pose():
     """The data flow of the reference's worker (`extract_matches`, inference_OnePosePlus_worker.py:7-37: model(data)
     then compute_query_pose_errors -> ransac_PnP on `mkpts_query_f` / `mkpts_3d_db`, metric_utils.py:221-270) through

@@ -1,0 +1,94 @@
+"""Training-step callers on the device: `onepose_plus_plus_amd.losses.Loss` (focal loss + its gradient in
+libopp_hip.so) against the reference-generated fixtures and, at the BASELINE configs[4] size, against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden.cases import LOSS_CASES, LOSS_CONFIG
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name", list(LOSS_CASES))
+def test_loss_vs_reference_fixture(name):
+    from onepose_plus_plus_amd.losses import Loss, fine_supervision
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    data, hp = H.loss_inputs(name)
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    data["conf_matrix"].requires_grad_(True)
+    data["expec_f"].requires_grad_(True)
+    fine_supervision(data, hp)
+    assert np.array_equal(data["expec_f_gt"].cpu().numpy(), gold["expec_f_gt"])
+    mod = Loss(dict(LOSS_CONFIG)).train()
+    mod(data)
+    sc = data["loss_scalars"]
+    assert abs(float(sc["loss_c"]) - float(gold["loss_c"])) <= 2e-6 * abs(float(gold["loss_c"]))
+    assert abs(float(sc["loss_f"]) - float(gold["loss_f"])) <= 2e-6 * abs(float(gold["loss_f"])) + 1e-12
+    assert abs(float(sc["loss"]) - float(gold["loss"])) <= 2e-6 * abs(float(gold["loss"]))
+    data["loss"].backward()
+    gc = data["conf_matrix"].grad.cpu().numpy()
+    ge = data["expec_f"].grad.cpu().numpy()
+    # elementwise: relative to each entry's own magnitude (entries on the clamp bounds reach 1e5), with an absolute floor
+    tol = 2e-6 * np.abs(gold["grad_conf"]) + 1e-9 * np.abs(gold["grad_conf"]).max()
+    assert (np.abs(gc - gold["grad_conf"]) <= tol).all(), np.abs(gc - gold["grad_conf"]).max()
+    assert np.array_equal(gc == 0, gold["grad_conf"] == 0)          # the clamp blocks exactly the same entries
+    assert np.abs(ge - gold["grad_expec"]).max() <= 2e-6 * max(np.abs(gold["grad_expec"]).max(), 1e-12)
+
+
+def test_focal_loss_ragged_sizes_and_gamma():
+    """n % 4 != 0 tails, a non-default gamma, a scaled upstream gradient, fp64-free comparison with the oracle on device."""
+    from oracle import loss_oracle as LO
+    from onepose_plus_plus_amd.losses import Loss
+    g = torch.Generator().manual_seed(4)
+    for shape, gamma, alpha in (((1, 7, 9), 2.0, 0.5), ((3, 5, 11), 1.5, 0.25), ((1, 1, 1), 2.0, 0.5), ((2, 33, 64), 3.0, 0.75)):
+        conf = torch.rand(shape, generator=g).cuda().requires_grad_(True)
+        gt = (torch.rand(shape, generator=g) < 0.1).to(torch.int16).cuda()
+        cfg = dict(LOSS_CONFIG, focal_gamma=gamma, focal_alpha=alpha, pos_weight=0.7, neg_weight=1.3)
+        loss = Loss(cfg).compute_coarse_loss(conf, gt)
+        (loss * 3.0).backward()
+        ref_c = conf.detach().double().requires_grad_(True)
+        ref = LO.coarse_focal_loss(ref_c, gt, None, alpha, gamma, 0.7, 1.3)
+        (ref * 3.0).backward()
+        assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach()))
+        err = (conf.grad.double() - ref_c.grad).abs()
+        assert (err <= 2e-6 * ref_c.grad.abs() + 1e-9 * ref_c.grad.abs().max()).all()
+
+
+def test_focal_loss_at_baseline_config5_size():
+    """B = 4, N = 7000, L = 4096 (115 M entries): value and gradient against the oracle evaluated on the device in fp32,
+    and the gradient's own invariants (zero outside the clamp, sign: positives pull conf up, negatives push it down)."""
+    from oracle import loss_oracle as LO
+    from onepose_plus_plus_amd.losses import Loss
+    B, N, L = 4, 7000, 4096
+    g = torch.Generator(device="cuda").manual_seed(11)
+    conf = torch.rand(B, N, L, generator=g, device="cuda") ** 4          # mostly small, like a real confidence matrix
+    gt = torch.zeros(B, N, L, dtype=torch.int16, device="cuda")
+    for b in range(B):
+        gt[b, torch.randperm(N, device="cuda")[:1500], torch.randperm(L, device="cuda")[:1500]] = 1
+    conf.requires_grad_(True)
+    mod = Loss(dict(LOSS_CONFIG))
+    loss = mod.compute_coarse_loss(conf, gt)
+    loss.backward()
+    grad = conf.grad
+    with torch.no_grad():
+        ref = LO.coarse_focal_loss(conf.detach(), gt, None, 0.5, 2.0, 1.0, 1.0)
+    assert abs(float(loss.detach()) - float(ref)) <= 1e-5 * abs(float(ref))
+    c = conf.detach()
+    inside = (c >= 1e-6) & (c <= 1 - 1e-6)
+    assert (grad[~inside] == 0).all()
+    assert (grad[(gt == 1) & inside] <= 0).all() and (grad[(gt == 0) & inside] >= 0).all()
+    n_pos, n_neg = int((gt == 1).sum()), int((gt == 0).sum())
+    assert n_pos == B * 1500 and n_pos + n_neg == B * N * L
+    # spot-check 4096 entries of the gradient against autograd of the oracle on those entries
+    idx = torch.randint(0, B * N * L, (4096,), device="cuda")
+    cs = c.view(-1)[idx].double().requires_grad_(True)
+    gs = gt.view(-1)[idx]
+    pos = (-0.5 * (1 - cs.clamp(1e-6, 1 - 1e-6)) ** 2 * cs.clamp(1e-6, 1 - 1e-6).log())[gs == 1].sum() / n_pos
+    neg = (-0.5 * cs.clamp(1e-6, 1 - 1e-6) ** 2 * (1 - cs.clamp(1e-6, 1 - 1e-6)).log())[gs == 0].sum() / n_neg
+    (pos + neg).backward()
+    err = (grad.view(-1)[idx].double() - cs.grad).abs()
+    assert (err <= 3e-6 * cs.grad.abs() + 1e-12).all()
