@@ -55,7 +55,7 @@ def reference_env():
     yield
     sys.path[:] = saved_path
     for k in list(sys.modules):
-        if k not in saved:
+        if k not in saved and not k.startswith("onepose_plus_plus_amd"):   # keep this package's modules (one identity)
             del sys.modules[k]
 
 
@@ -135,7 +135,8 @@ def test_reference_lightning_module_builds_on_the_hip_matcher_and_loss(reference
 def test_install_without_reference_modules_registers_both_paths():
     """On a box without the reference checkout the aliases are still importable (what the GPU tests use)."""
     from onepose_plus_plus_amd import OnePosePlus_model, dropin
-    saved = {k: sys.modules.get(k) for k in ("src", "src.models", "src.models.OnePosePlus", "src.models.OnePosePlus.OnePosePlusModel")}
+    saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.")}
+    saved_path = list(sys.path)
     try:
         for k in saved:
             sys.modules.pop(k, None)
@@ -147,7 +148,7 @@ def test_install_without_reference_modules_registers_both_paths():
         assert A is OnePosePlus_model and B is OnePosePlus_model
         sys.path[:] = old
     finally:
-        for k, v in saved.items():
-            sys.modules.pop(k, None)
-            if v is not None:
-                sys.modules[k] = v
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:     # every stand-in install() registered
+            del sys.modules[k]
+        sys.modules.update(saved)
