@@ -84,3 +84,56 @@ def run_sharded(objects, forward_fn, group=None, dst=0):
     mine = shard_objects(names, rank, world)
     local = {n: forward_fn(n, objects[n]) for n in mine}
     return gather_results(local, dst=dst, group=group)
+
+
+class GradientAverager:
+    """Data-parallel training (BASELINE configs[4]; the reference wraps `PL_OnePosePlus` in Lightning DDP,
+    train_onepose_plus.py): every rank runs the training step on its own B = 4 samples, then the gradients are averaged.
+
+    The 144 parameter gradients (40.9 MB fp32) live in ONE flat buffer - each `p.grad` is a view into it - so a step needs
+    ONE all-reduce over xGMI (per-link bound ring: one large message instead of DDP's 25 MB buckets and their per-bucket
+    latency) and no copy in or out:
+
+        avg = GradientAverager(model)          # after model.cuda(), before the first backward
+        loss.backward(); avg.average(); optimiser.step(); avg.zero()
+
+    No SyncBN, like the reference (plain nn.BatchNorm2d, backbone/resnet.py:25-26): BatchNorm statistics stay per rank.
+    """
+
+    def __init__(self, module, group=None):
+        self.group = group
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("parameters must share one device and dtype")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates into the view in place
+            off += n
+
+    def zero(self):
+        """use instead of optimiser.zero_grad(set_to_none=True), which would detach the views"""
+        self.flat.zero_()
+
+    def attached(self):
+        """True while every p.grad still is its view of the flat buffer"""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                return False
+            off += p.numel()
+        return True
+
+    def average(self):
+        """one all-reduce of the flat buffer; afterwards every rank holds the mean gradient"""
+        if not self.attached():
+            raise RuntimeError("a parameter's .grad was replaced (zero_grad(set_to_none=True)?): call zero() instead")
+        world = dist.get_world_size(self.group)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(world)
+        return self.flat

@@ -75,3 +75,66 @@ def test_partition_helpers():
     ch = chunk_index(10, 3)
     assert sum(ch, []) == list(range(10)) and [len(c) for c in ch] == [4, 3, 3]
     assert chunk_index(2, 4) == [[0], [1], [], []]
+
+
+def _train_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from onepose_plus_plus_amd.sharding import GradientAverager
+        cfg = default_config()
+        model = OnePosePlus_model(cfg).train()
+        broadcast_weights(model, make_state_dict(cfg, 0) if rank == 0 else None, src=0)
+        avg = GradientAverager(model)
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        opt = torch.optim.SGD(model.parameters(), lr=0.5)
+
+        def weights(r):                               # rank-dependent pseudo-loss: grad of p = w_r(p)
+            g = torch.Generator().manual_seed(1000 + r)
+            return [torch.randn(p.shape, generator=g) for p in avg.params]
+
+        loss = sum((p * w).sum() for p, w in zip(avg.params, weights(rank)))
+        loss.backward()
+        attached_after_backward = avg.attached()
+        own = [p.grad.clone() for p in avg.params]
+        avg.average()
+        want = [sum(weights(r)[i] for r in range(world)) / world for i in range(len(avg.params))]
+        mean_ok = all(torch.allclose(p.grad, w, rtol=0, atol=1e-6) for p, w in zip(avg.params, want))
+        own_ok = all(torch.equal(o, w) for o, w in zip(own, weights(rank)))
+        opt.step()
+        digest = float(sum(p.detach().double().sum() for p in avg.params))
+        avg.zero()
+        zero_ok = all(float(p.grad.abs().max()) == 0.0 for p in avg.params) and avg.attached()
+        opt.zero_grad(set_to_none=True)               # detaches the views -> average() must refuse
+        try:
+            avg.average()
+            refused = False
+        except RuntimeError:
+            refused = True
+        q.put((rank, len(names), int(avg.flat.numel()), attached_after_backward, own_ok, mean_ok, zero_ok, refused, digest))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_averager_world2():
+    """Data-parallel training step: ONE all-reduce of the flat 40.9 MB gradient buffer, identical parameters afterwards."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+    assert set(res) == {0, 1}
+    for r in (0, 1):
+        n, numel, attached, own_ok, mean_ok, zero_ok, refused, _ = res[r]
+        assert n == 144 and numel * 4 > 40e6                       # the whole model in one buffer
+        assert attached and own_ok and mean_ok and zero_ok and refused
+    assert res[0][-1] == res[1][-1]                                 # same parameters on both ranks after the step
