@@ -279,10 +279,11 @@ int opp_debug_timestamps(void* buf);
 /* ---- live kernel timing for bench.py's roofline leg ---------------------------------------
  * Arms HIP-event timing (events recorded on the launch stream) of every launch of ONE kernel symbol:
  *   tile_cfg < 1000: a GEMM tile configuration (0 128x128/4 waves, 1 64x128, 2 64x64, 10/11 deeper prefetch,
- *                    25 128x128/8 waves, 26 64x128/8 waves, 30 64x256/8 waves + fused LayerNorm) of
+ *                    20 256x128/8 waves, 22 128x256/8 waves, 25 128x128/8 waves, 26 64x128/8 waves, 30 64x256/8 waves + fused LayerNorm) of
  *                    kind 0 dense GEMM, 1 implicit-GEMM conv, 2 coarse score GEMM with fused softmax statistics;
  *   tile_cfg 1000 linear-attention KV gather, 1001 linear-attention apply, 1002 dual-softmax confidence pass,
- *            1003 the whole fine stage (kind ignored).
+ *            1003 the whole fine stage, 1004 fine-level attention (one workgroup per match), 1005 window gather,
+ *            1006 fine head, 1007 / 1008 focal loss forward / backward (kind ignored).
  * opp_profile_stop synchronises and returns the summed time, the summed ALGORITHMIC work (FLOPs with unpadded
  * channel counts for GEMMs, bytes for the 1000+ symbols) and the number of launches measured. */
 int opp_profile_start(int tile_cfg, int kind, int capacity_launches);
