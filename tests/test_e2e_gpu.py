@@ -321,6 +321,54 @@ def test_e2e_vs_oracle_and_determinism(precision):
         assert torch.equal(v, data[k]), k
 
 
+RANDOM_SHAPES = [(s, 8 * (4 + (s * 7) % 17), 8 * (4 + (s * 11) % 15), 3 + (s * 37) % 401, (0.0, 0.02, 0.05)[s % 3]) for s in range(12)]
+
+
+@pytest.mark.parametrize("seed,h,w,n,thr", RANDOM_SHAPES)
+def test_random_shapes_vs_oracle(seed, h, w, n, thr):
+    """Ragged shapes nobody tuned for (H, W any multiple of 8 in 32..160, N = 3..403, anisotropic image scales):
+    full coarse-to-fine forward against the pinned oracle.  The whole confidence matrix within 1e-4; the match set
+    identical, where a pair may differ only if the ORACLE's own decision is marginal (confidence within 1e-4 of the
+    threshold, or of the runner-up in its row / column)."""
+    from oracle import onepose_oracle as O
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
+    cfg = default_config(thr=thr)
+    sd = make_state_dict(cfg, 100 + seed)
+    data = make_inputs(n, (h, w), 200 + seed)
+    data["query_image_scale"] = torch.tensor([[1.0 + 0.125 * (seed % 4), 1.0 - 0.0625 * (seed % 5)]])
+    out = ops.run_model(ops.make_model(cfg, sd), data)
+    ref = {k: v.clone() for k, v in data.items()}
+    O.forward(sd, ref, cfg)
+    conf_o = ref["conf_matrix"][0]
+    conf_h = out["conf_matrix"][0].cpu()
+    assert conf_h.shape == conf_o.shape == (n, (h // 8) * (w // 8))
+    assert (conf_h - conf_o).abs().max() <= H.TOL_CONF
+    pairs_o = set(zip(ref["i_ids"].tolist(), ref["j_ids"].tolist()))
+    pairs_h = set(zip(out["i_ids"].tolist(), out["j_ids"].tolist()))
+    top2_r = conf_o.topk(min(2, conf_o.shape[1]), dim=1).values
+    top2_c = conf_o.topk(min(2, conf_o.shape[0]), dim=0).values
+    for (i, j) in pairs_o ^ pairs_h:
+        c = float(conf_o[i, j])
+        marginal = abs(c - thr) <= 1e-4
+        marginal |= top2_r.shape[1] > 1 and float(top2_r[i, 0] - top2_r[i, 1]) <= 1e-4
+        marginal |= top2_c.shape[0] > 1 and float(top2_c[0, j] - top2_c[1, j]) <= 1e-4
+        assert marginal, (seed, i, j, c)
+    common = sorted(pairs_o & pairs_h)
+    assert len(common) >= len(pairs_o) - 2
+    if common:
+        io = {p: k for k, p in enumerate(zip(ref["i_ids"].tolist(), ref["j_ids"].tolist()))}
+        ih = {p: k for k, p in enumerate(zip(out["i_ids"].tolist(), out["j_ids"].tolist()))}
+        ko, kh = [io[p] for p in common], [ih[p] for p in common]
+        assert (out["mconf"].cpu()[kh] - ref["mconf"][ko]).abs().max() <= H.TOL_CONF
+        assert (out["expec_f"].cpu()[kh, :2] - ref["expec_f"][ko, :2]).abs().max() <= H.TOL_OFFSET
+        assert (out["expec_f"].cpu()[kh, 2] - ref["expec_f"][ko, 2]).abs().max() <= H.TOL_OFFSET * H.STD_TOL_FACTOR
+        assert (out["mkpts_query_f"].cpu()[kh] - ref["mkpts_query_f"][ko]).abs().max() <= H.TOL_PIXEL
+        assert torch.equal(out["mkpts_3d_db"].cpu()[kh], ref["mkpts_3d_db"][ko])
+    assert (out["i_ids"][1:] >= out["i_ids"][:-1]).all()
+
+
 @pytest.mark.parametrize("n,precision", [(5000, "bf16x3"), (5000, "fp32"), (5000, "fp16x2"), (5000, "fp16x2_all"), (15000, "bf16x3"), (15000, "fp32"), (15000, "fp16x2_all")])
 def test_full_size_properties(n, precision):
     """BASELINE sizes: properties that hold for any input (no oracle needed)."""
