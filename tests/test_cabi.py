@@ -86,3 +86,36 @@ def test_conv_packed_k(lib):
     assert lib.opp_conv_packed_k(97, 3) == (3 * 9 + 2) * 32
     assert lib.opp_conv_packed_k(101, 3) == 9 * 128        # five tail channels do not fit 4 per tap
     assert lib.opp_conv_packed_k(4, 3) == 9 * 32           # no full group to attach the tail to
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """`include/opp_hip.h` compiles as C99 and as C++ (no torch / HIP types in the signatures), and a C program links
+    against libopp_hip.so and calls host-only entry points (what a cgo / JNI / N-API binding would do)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    gxx = shutil.which("g++")
+    if not gcc or not gxx:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    libdir = os.path.join(root, "onepose_plus_plus_amd")
+    src = tmp_path / "use.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "opp_hip.h"\n'
+        "int main(void) {\n"
+        "  opp_config cfg; (void)cfg;\n"
+        '  printf("%d %d %zu\\n", opp_conv_packed_k(196, 3), opp_conv_packed_k(128, 3), opp_focal_loss_workspace_bytes((size_t)1 << 20));\n'
+        "  /* a NULL handle is an argument error, reported through the C error channel */\n"
+        "  int rc = opp_num_weights(NULL);\n"
+        '  printf("%d\\n", rc);\n'
+        "  return 0;\n}\n")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    cpp = tmp_path / "use.cpp"
+    cpp.write_text('#include "opp_hip.h"\nint main() { return opp_conv_packed_k(4, 3) == 288 ? 0 : 1; }\n')
+    subprocess.run([gxx, "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)], check=True)
+    exe = tmp_path / "use"
+    subprocess.run([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lopp_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "1792" and out[1] == "1152" and int(out[2]) > 0
