@@ -196,6 +196,14 @@ int opp_focal_loss_forward(const float* conf, const short* conf_gt, const float*
 int opp_focal_loss_backward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
                             float gamma, const float* scales, float* grad_conf, void* stream);
 
+/* backward of conf = A * B, A = softmax(S, dim = points), B = softmax(S, dim = cells) (utils/coarse_matching.py:115);
+ * sim, grad_conf, grad_sim [B][N][L]; lse_row [B][N] = logsumexp_j S_ij, lse_col [B][L] = logsumexp_i S_ij:
+ *   grad_sim_ij = 2 conf_ij g_ij - A_ij sum_i' g_i'j conf_i'j - B_ij sum_j' g_ij' conf_ij'. */
+size_t opp_dual_softmax_backward_workspace_bytes(int B, int N, int L);
+int opp_dual_softmax_backward(const float* grad_conf, const float* sim, const float* lse_row, const float* lse_col,
+                              int B, int N, int L, float* grad_sim, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

@@ -1268,6 +1268,13 @@ extern "C" int opp_focal_loss_backward(const float* conf, const short* conf_gt, 
   return opp_focal_loss_bwd(conf, conf_gt, weight, n, alpha, gamma, scales, grad_conf, (hipStream_t)stream);
 }
 
+extern "C" size_t opp_dual_softmax_backward_workspace_bytes(int B, int N, int L) { return opp_dual_softmax_bwd_ws_bytes(B, N, L); }
+
+extern "C" int opp_dual_softmax_backward(const float* grad_conf, const float* sim, const float* lse_row, const float* lse_col, int B,
+                                         int N, int L, float* grad_sim, void* ws, size_t ws_bytes, void* stream) {
+  return opp_dual_softmax_bwd(grad_conf, sim, lse_row, lse_col, B, N, L, grad_sim, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int opp_conv_packed_k(int cin, int ks) { return opp_conv_k(cin, ks); }
 
 extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {

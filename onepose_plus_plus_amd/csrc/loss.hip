@@ -127,6 +127,101 @@ __global__ __launch_bounds__(kLossThreads) void focal_bwd_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Backward of the dual-softmax confidence matrix (CoarseMatching.forward, utils/coarse_matching.py:115):
+//   conf = A * B,  A = softmax(S) over the N points (per cell j),  B = softmax(S) over the L cells (per point i)
+//   dS_ij = 2 conf_ij g_ij - A_ij c_j - B_ij r_i,   c_j = sum_i g_ij conf_ij,   r_i = sum_j g_ij conf_ij
+// (softmax backward P (g' - sum g' P) with g' = g times the other factor; both inner sums are sums of g conf).
+// A and B are re-evaluated from S and the log-sum-exps lse_col [B][L], lse_row [B][N] (A = exp(S - lse_col_j)), so only
+// S is kept for the backward - autograd keeps both softmax outputs and the product (3 x 460 MB at B = 4, N = 7000) and
+// makes ~10 passes.  Here: one pass for the row / column sums (fixed-order partials, deterministic), one elementwise.
+// ---------------------------------------------------------------------------------------
+constexpr int kDsmRows = 64;                 // rows per block (16 per wave)
+template <int VEC>
+__global__ __launch_bounds__(256) void dsm_sums_kernel(const float* __restrict__ g, const float* __restrict__ sim,
+                                                       const float* __restrict__ lse_row, const float* __restrict__ lse_col,
+                                                       int N, int L, int col_tiles, float* __restrict__ rpart,
+                                                       float* __restrict__ cpart) {
+  __shared__ float csh[4][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, rb = blockIdx.x, ct = blockIdx.y;
+  const int j0 = ct * 64 * VEC + lane * VEC;
+  const size_t base = (size_t)b * N * L;
+  float cs[VEC], lc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    cs[e] = 0.f;
+    lc[e] = (j0 + e < L) ? lse_col[(size_t)b * L + j0 + e] : 0.f;
+  }
+  for (int rr = wave; rr < kDsmRows; rr += 4) {
+    const int row = rb * kDsmRows + rr;
+    if (row >= N) break;                     // wave-uniform
+    const float lr = lse_row[(size_t)b * N + row];
+    float rs = 0.f;
+    if (j0 < L) {
+      const size_t o = base + (size_t)row * L + j0;
+      float gv[VEC], sv[VEC];
+      if (VEC == 4) {
+        const float4 a = *reinterpret_cast<const float4*>(g + o), s4 = *reinterpret_cast<const float4*>(sim + o);
+        gv[0] = a.x; gv[1 % VEC] = a.y; gv[2 % VEC] = a.z; gv[3 % VEC] = a.w;
+        sv[0] = s4.x; sv[1 % VEC] = s4.y; sv[2 % VEC] = s4.z; sv[3 % VEC] = s4.w;
+      } else {
+        gv[0] = g[o];
+        sv[0] = sim[o];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float p = gv[e] * (expf(sv[e] - lc[e]) * expf(sv[e] - lr));      // g * conf
+        cs[e] += p;
+        rs += p;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rs += __shfl_xor(rs, o, 64);
+    if (lane == 0) rpart[((size_t)b * N + row) * col_tiles + ct] = rs;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) csh[wave][lane * VEC + e] = cs[e];
+  __syncthreads();
+  const int nrb = gridDim.x;
+  for (int t = threadIdx.x; t < 64 * VEC; t += 256) {
+    const int j = ct * 64 * VEC + t;
+    if (j < L) cpart[((size_t)b * nrb + rb) * L + j] = ((csh[0][t] + csh[1][t]) + csh[2][t]) + csh[3][t];
+  }
+}
+
+// r[b][row] = sum over column tiles ; c[b][col] = sum over row blocks (fixed order)
+__global__ void dsm_reduce_kernel(const float* __restrict__ rpart, const float* __restrict__ cpart, int B, int N, int L,
+                                  int col_tiles, int row_blocks, float* __restrict__ r, float* __restrict__ c) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nr = (size_t)B * N, nc = (size_t)B * L;
+  if (i < nr) {
+    float s = 0.f;
+    for (int t = 0; t < col_tiles; ++t) s += rpart[i * col_tiles + t];
+    r[i] = s;
+  } else if (i < nr + nc) {
+    const size_t k = i - nr;
+    const size_t b = k / L, j = k - b * L;
+    float s = 0.f;
+    for (int q = 0; q < row_blocks; ++q) s += cpart[(b * row_blocks + q) * L + j];
+    c[k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void dsm_apply_kernel(const float* __restrict__ g, const float* __restrict__ sim,
+                                                        const float* __restrict__ lse_row, const float* __restrict__ lse_col,
+                                                        int N, int L, size_t total, const float* __restrict__ r,
+                                                        const float* __restrict__ c, float* __restrict__ ds) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / L;                // = b * N + row
+    const size_t col = (row / N) * L + (i - row * L);
+    const float s = sim[i];
+    const float A = expf(s - lse_col[col]), Bv = expf(s - lse_row[row]);
+    ds[i] = 2.0f * (A * Bv) * g[i] - A * c[col] - Bv * r[row];
+  }
+}
+
 int loss_blocks(size_t n) {
   const size_t want = (n / 4 + kLossThreads * 8 - 1) / (kLossThreads * 8);
   return (int)(want < 1 ? 1 : (want > kLossMaxBlocks ? kLossMaxBlocks : want));
@@ -164,5 +259,53 @@ int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, 
   hipLaunchKernelGGL(focal_bwd_kernel, dim3(loss_blocks(n)), dim3(kLossThreads), 0, stream, conf, gt, weight, n, alpha, gamma, scales,
                      grad);
   OPP_CHECK_LAUNCH("focal_loss backward");
+  return OPP_OK;
+}
+
+namespace {
+struct DsmPlan {
+  int vec, col_tiles, row_blocks;
+  size_t rpart, cpart, r, c, total;   // float counts
+};
+DsmPlan dsm_plan(int B, int N, int L) {
+  DsmPlan p;
+  p.vec = (L % 4 == 0) ? 4 : 1;
+  p.col_tiles = (L + 64 * p.vec - 1) / (64 * p.vec);
+  p.row_blocks = (N + kDsmRows - 1) / kDsmRows;
+  p.rpart = (size_t)B * N * p.col_tiles;
+  p.cpart = (size_t)B * p.row_blocks * L;
+  p.r = (size_t)B * N;
+  p.c = (size_t)B * L;
+  p.total = p.rpart + p.cpart + p.r + p.c;
+  return p;
+}
+}  // namespace
+
+size_t opp_dual_softmax_bwd_ws_bytes(int B, int N, int L) { return dsm_plan(B, N, L).total * sizeof(float) + 64; }
+
+int opp_dual_softmax_bwd(const float* g, const float* sim, const float* lse_row, const float* lse_col, int B, int N, int L,
+                         float* ds, void* ws, size_t ws_bytes, hipStream_t stream) {
+  OPP_CHECK_ARG(g && sim && lse_row && lse_col && ds && ws && B > 0 && N > 0 && L > 0, "dual_softmax backward: null argument / empty input");
+  const DsmPlan p = dsm_plan(B, N, L);
+  OPP_CHECK_ARG(ws_bytes >= p.total * sizeof(float), "dual_softmax backward: workspace too small");
+  OPP_CHECK_ARG(p.vec == 1 || (aligned16(g) && aligned16(sim)), "dual_softmax backward: operands must be 16-byte aligned");
+  OPP_CHECK_ARG(B <= 65535 && p.col_tiles <= 65535, "dual_softmax backward: grid too large");
+  float* rpart = static_cast<float*>(ws);
+  float* cpart = rpart + p.rpart;
+  float* r = cpart + p.cpart;
+  float* c = r + p.r;
+  const dim3 grid(p.row_blocks, p.col_tiles, B);
+  if (p.vec == 4)
+    hipLaunchKernelGGL(dsm_sums_kernel<4>, grid, dim3(256), 0, stream, g, sim, lse_row, lse_col, N, L, p.col_tiles, rpart, cpart);
+  else
+    hipLaunchKernelGGL(dsm_sums_kernel<1>, grid, dim3(256), 0, stream, g, sim, lse_row, lse_col, N, L, p.col_tiles, rpart, cpart);
+  const size_t nred = p.r + p.c;
+  hipLaunchKernelGGL(dsm_reduce_kernel, dim3((unsigned)((nred + 255) / 256)), dim3(256), 0, stream, rpart, cpart, B, N, L, p.col_tiles,
+                     p.row_blocks, r, c);
+  const size_t total = (size_t)B * N * L;
+  const size_t want = (total + 256 * 8 - 1) / (256 * 8);
+  hipLaunchKernelGGL(dsm_apply_kernel, dim3((unsigned)(want > 4096 ? 4096 : (want < 1 ? 1 : want))), dim3(256), 0, stream, g, sim, lse_row,
+                     lse_col, N, L, total, r, c, ds);
+  OPP_CHECK_LAUNCH("dual_softmax backward");
   return OPP_OK;
 }

@@ -46,6 +46,9 @@ int opp_focal_loss_fwd(const float* conf, const short* gt, const float* weight, 
                        void* ws, size_t ws_bytes, hipStream_t stream);
 int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma,
                        const float* scales, float* grad, hipStream_t stream);
+size_t opp_dual_softmax_bwd_ws_bytes(int B, int N, int L);
+int opp_dual_softmax_bwd(const float* g, const float* sim, const float* lse_row, const float* lse_col, int B, int N, int L, float* ds,
+                         void* ws, size_t ws_bytes, hipStream_t stream);
 // many short segment pairs (fine level: 25 window tokens + 1 point token per match): KV, Ksum and the apply of both
 // streams of one segment in one workgroup
 bool opp_linattn_small_ok(int len0, int len1, int C, int D);

@@ -106,6 +106,43 @@ def _transformer(p, name, tcfg, f3, f2, mask=None):      # loftr_module/transfor
     return f3, f2
 
 
+class DualSoftmax(torch.autograd.Function):
+    """conf = softmax(S, dim=1) * softmax(S, dim=2) for S [B, N, L] (utils/coarse_matching.py:115) with a hand-written
+    backward: only S and its two log-sum-exps are kept (autograd would keep both softmax outputs and the product - three
+    B x N x L tensors), and on the device d loss / dS comes from `opp_dual_softmax_backward` (csrc/loss.hip):
+        dS_ij = 2 conf_ij g_ij - A_ij sum_i' g_i'j conf_i'j - B_ij sum_j' g_ij' conf_ij'
+    CPU tensors (the CPU tests of this module) evaluate the same formula with torch ops."""
+
+    @staticmethod
+    def forward(ctx, sim):
+        lse_col = torch.logsumexp(sim, dim=1)              # over the points i, per cell j     [B, L]
+        lse_row = torch.logsumexp(sim, dim=2)              # over the cells j, per point i     [B, N]
+        ctx.save_for_backward(sim, lse_row, lse_col)
+        return torch.exp(sim - lse_col[:, None, :]) * torch.exp(sim - lse_row[:, :, None])
+
+    @staticmethod
+    def backward(ctx, g):
+        sim, lse_row, lse_col = ctx.saved_tensors
+        if sim.is_cuda and sim.dtype == torch.float32:
+            from . import _lib
+            lib = _lib.load()
+            B, N, L = sim.shape
+            s, gc = sim.contiguous(), g.to(torch.float32).contiguous()
+            lr, lc = lse_row.contiguous(), lse_col.contiguous()
+            ds = torch.empty_like(s)
+            ws = torch.empty(lib.opp_dual_softmax_backward_workspace_bytes(B, N, L), dtype=torch.uint8, device=s.device)
+            with torch.cuda.device(s.device):
+                _lib.check(lib.opp_dual_softmax_backward(gc.data_ptr(), s.data_ptr(), lr.data_ptr(), lc.data_ptr(), B, N, L,
+                                                         ds.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         torch.cuda.current_stream(s.device).cuda_stream),
+                           "opp_dual_softmax_backward")
+            return ds
+        A = torch.exp(sim - lse_col[:, None, :])
+        Bm = torch.exp(sim - lse_row[:, :, None])
+        gc = g * A * Bm
+        return 2.0 * gc - A * gc.sum(1, keepdim=True) - Bm * gc.sum(2, keepdim=True)
+
+
 def differentiable_forward(p, cfg, inputs, matches, pe, bn_eval_stats=None):
     """-> (conf_matrix [B,N,L], expec_f [M',3] or None) as differentiable functions of the parameter dict `p`.
     `inputs`: query_image, keypoints3d, descriptors3d_db, descriptors3d_coarse_db (or None), query_image_mask [B,L] or
@@ -124,7 +161,7 @@ def differentiable_forward(p, cfg, inputs, matches, pe, bn_eval_stats=None):
     sim = torch.einsum("nlc,nsc->nls", f3 / C ** 0.5, f2 / C ** 0.5) / (cfg["coarse_matching"]["dual_softmax"]["temperature"] + 1e-4)
     if mask is not None:                                      # coarse_matching.py:108-114
         sim = sim + torch.where(mask[:, None].bool(), 0.0, -1e9).to(sim.dtype)
-    conf = F.softmax(sim, 1) * F.softmax(sim, 2)              # coarse_matching.py:115
+    conf = DualSoftmax.apply(sim)                              # coarse_matching.py:115
     if not cfg["fine_matching"]["enable"]:
         return conf, None
     b_ids, i_ids, j_ids = matches

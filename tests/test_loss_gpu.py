@@ -92,3 +92,49 @@ def test_focal_loss_at_baseline_config5_size():
     (pos + neg).backward()
     err = (grad.view(-1)[idx].double() - cs.grad).abs()
     assert (err <= 3e-6 * cs.grad.abs() + 1e-12).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 192), (1, 77, 25), (3, 65, 130), (1, 5, 4), (2, 129, 1028)])
+def test_dual_softmax_backward_vs_autograd(shape):
+    """`train_autograd.DualSoftmax` on the device (opp_dual_softmax_backward) against torch.autograd of
+    softmax(S, 1) * softmax(S, 2) in fp64, masked cells (-1e9) included; L % 4 != 0 takes the scalar path."""
+    import torch.nn.functional as F
+    from onepose_plus_plus_amd.train_autograd import DualSoftmax
+    g = torch.Generator().manual_seed(sum(shape))
+    S = torch.randn(shape, generator=g) * 4.0
+    S[:, :, ::7] -= 1e9                                                   # query_image_mask (coarse_matching.py:108-114)
+    go = torch.randn(shape, generator=g)
+    ref_s = S.double().requires_grad_(True)
+    (F.softmax(ref_s, 1) * F.softmax(ref_s, 2) * go.double()).sum().backward()
+    dev_s = S.cuda().requires_grad_(True)
+    conf = DualSoftmax.apply(dev_s)
+    (conf * go.cuda()).sum().backward()
+    with torch.no_grad():
+        want = F.softmax(ref_s, 1) * F.softmax(ref_s, 2)
+    assert (conf.detach().cpu().double() - want).abs().max() <= 5e-6      # fp32 exp of S - lse with |S - lse| up to ~25
+    err = (dev_s.grad.cpu().double() - ref_s.grad).abs().max()
+    assert err <= 2e-6 * max(1.0, float(ref_s.grad.abs().max())), float(err)
+    assert (dev_s.grad[:, :, ::7] == 0).all()                             # masked cells get no gradient
+    # deterministic: fixed-order partial sums
+    dev2 = S.cuda().requires_grad_(True)
+    (DualSoftmax.apply(dev2) * go.cuda()).sum().backward()
+    assert torch.equal(dev2.grad, dev_s.grad)
+
+
+def test_dual_softmax_backward_at_baseline_config5_size():
+    """B = 4, N = 7000, L = 4096: against the same formula in torch ops on the device (fp32), spot rows in fp64."""
+    from onepose_plus_plus_amd.train_autograd import DualSoftmax
+    B, N, L = 4, 7000, 4096
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    S = (torch.randn(B, N, L, generator=gen, device="cuda") * 3.0).requires_grad_(True)
+    go = torch.randn(B, N, L, generator=gen, device="cuda")
+    conf = DualSoftmax.apply(S)
+    (conf * go).sum().backward()
+    with torch.no_grad():
+        s64 = S.detach()[1, :, :].double()                 # one sample in fp64: its sums only involve that sample
+        A = torch.softmax(s64, 0)
+        Bm = torch.softmax(s64, 1)
+        gc = go[1].double() * A * Bm
+        want = 2 * gc - A * gc.sum(0, keepdim=True) - Bm * gc.sum(1, keepdim=True)
+        err = (S.grad[1].double() - want).abs().max()
+        assert err <= 1e-5 * float(want.abs().max()), (float(err), float(want.abs().max()))
