@@ -1,5 +1,7 @@
 """Where the training step (bench.py train_leg: BASELINE configs[4] per-GPU shape) spends its device time:
-torch.profiler table of one step (HIP forward, fine_supervision, Loss, PyTorch-ops backward, AdamW)."""
+torch.profiler table of one train_leg pass (HIP forward, fine_supervision, Loss, backward, AdamW; the pass also
+contains the forward-only and loss-only timings of that leg).
+    python tools/train_probe.py > gpurun_out/train_probe.txt"""
 import os
 import sys
 
@@ -13,12 +15,7 @@ import bench  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    holder = {}
-    real_timed = None
-
-    # reuse train_leg's construction: run it once for warm-up, keeping its closures through a tiny hook
-    import onepose_plus_plus_amd.losses as L
-    r = bench.train_leg(torch, dev, "bf16x3", nsteps=1)
+    r = bench.train_leg(torch, dev, "bf16x3", nsteps=1)          # warm-up (allocator, MIOpen find)
     print({k: v for k, v in r.items() if k in ("forward_ms", "step_ms")}, flush=True)
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         bench.train_leg(torch, dev, "bf16x3", nsteps=1)
