@@ -37,3 +37,24 @@ def test_autograd_function_is_wired_into_training_mode():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"query_image": torch.zeros(2, 1, 64, 64)})
     assert hasattr(TA.TrainForward, "apply")
+
+
+def test_dual_softmax_formula_matches_autograd():
+    """`DualSoftmax` (the hand-written backward formula; on CPU tensors evaluated with torch ops, on the device by
+    opp_dual_softmax_backward) against torch.autograd of softmax(S, 1) * softmax(S, 2) in fp64, masked cells included."""
+    import torch.nn.functional as F
+    from onepose_plus_plus_amd.train_autograd import DualSoftmax
+    g = torch.Generator().manual_seed(0)
+    for shape in ((2, 7, 5), (1, 30, 12), (3, 4, 25)):
+        S = (torch.randn(shape, generator=g, dtype=torch.float64) * 3).requires_grad_(True)
+        go = torch.randn(shape, generator=g, dtype=torch.float64)
+        S.data[0, :, :2] -= 1e9
+        c1 = F.softmax(S, 1) * F.softmax(S, 2)
+        (c1 * go).sum().backward()
+        g1 = S.grad.clone()
+        S.grad = None
+        c2 = DualSoftmax.apply(S)
+        (c2 * go).sum().backward()
+        assert (c1 - c2).abs().max() <= 1e-14
+        assert (g1 - S.grad).abs().max() <= 1e-14
+        assert (S.grad[0, :, :2] == 0).all()
