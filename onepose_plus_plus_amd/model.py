@@ -506,146 +506,173 @@ class OnePosePlus_model(nn.Module):
         hc, wc, hf, wf = H // 8, W // 8, H // 2, W // 2
         L = hc * wc
         dC, dF = cfg["loftr_coarse"]["d_model"], cfg["loftr_fine"]["d_model"]
-        with torch.cuda.device(device):
-            self._rt["dirty"] = True                      # parameters change between training steps: always repack
-            lib, ctx = self._ensure_ready(device)
-            stream = torch.cuda.current_stream(device).cuda_stream
-            data.update({"bs": B, "q_hw_i": img.shape[2:], "q_hw_c": torch.Size([hc, wc]), "q_hw_f": torch.Size([hf, wf])})
-            img_c = self._f32(img, "query_image", device)
-            kpts = self._f32(data["keypoints3d"], "keypoints3d", device)
-            bank_f = self._f32(data["descriptors3d_db"], "descriptors3d_db", device)
-            bank_c = bank_f if "descriptors3d_coarse_db" not in data else \
-                self._f32(data["descriptors3d_coarse_db"], "descriptors3d_coarse_db", device)
-            N = int(kpts.shape[1])
-            if kpts.shape[0] != B or tuple(bank_c.shape) != (B, dC, N):
-                raise RuntimeError("bad point-cloud shapes: keypoints3d %s, coarse bank %s" % (tuple(kpts.shape), tuple(bank_c.shape)))
-            qscale = self._f32(data["query_image_scale"], "query_image_scale", device) if "query_image_scale" in data else None
-            mask = None
-            if "query_image_mask" in data:
-                if tuple(data["query_image_mask"].shape) != (B, hc, wc):
-                    raise RuntimeError("query_image_mask must have the coarse resolution [B, %d, %d]" % (hc, wc))
-                mask = data["query_image_mask"].flatten(-2).to(device=device, dtype=torch.float32).contiguous()
-            pe = self._pe_tokens(hc, wc, device) if self.dense_pos_encoding is not None else None
+        if self.gemm_precision in ("fp16x2", "fp16x2_all"):
+            # the narrower opt-in fast mode is an inference option: its range guard re-runs a forward, which a training
+            # step (running statistics already updated, random draws consumed) cannot do
+            raise RuntimeError("train() mode runs in 'bf16x3' or 'fp32'; gemm_precision %r is inference-only" % (self.gemm_precision,))
+        try:
+            with torch.cuda.device(device):
+                self._forward_train_impl(data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF)
+        finally:
+            # parameters and running statistics move between training steps: on EVERY exit path the eval packing
+            # (folded BatchNorm) and the cached 3D-point tokens (keypoint-MLP weights) of this module are stale
+            self._rt["dirty"] = True
+            self._rt["obj"] = None
 
-            # 1. backbone (OnePosePlusModel.py:109-128); a frozen pretrained backbone stays in eval mode (:109-113)
-            feat_c = torch.empty((B, L, dC), dtype=torch.float32, device=device)
-            feat_f = torch.empty((B, hf * wf, dF), dtype=torch.float32, device=device)
-            frozen = bool(self.loftr_backbone_pretrained) and bool(cfg["loftr_backbone"]["pretrained_fix"])
-            if frozen:
-                nb = lib.opp_backbone_workspace_bytes(ctx, H, W)
-                ws = self._workspace(nb, device)
-                for b in range(B):
-                    _lib.check(lib.opp_backbone(ctx, img_c[b].data_ptr(), H, W, feat_c[b].data_ptr(), feat_f[b].data_ptr(),
-                                                ws.data_ptr(), ws.numel(), stream), "opp_backbone")
-            else:
-                self._ensure_train_packed(lib, ctx, device)
-                n_bn = lib.opp_num_bn_layers(ctx)
-                stats = torch.zeros((n_bn, 512), dtype=torch.float32, device=device)
-                nb = lib.opp_backbone_train_workspace_bytes(ctx, B, H, W)
-                ws = self._workspace(nb, device)
-                _lib.check(lib.opp_backbone_train(ctx, img_c.data_ptr(), B, H, W, feat_c.data_ptr(), feat_f.data_ptr(),
-                                                  stats.data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_backbone_train")
-                with torch.no_grad():                  # running statistics, like torch.nn.BatchNorm2d in train()
-                    m = self.bn_momentum
-                    for i in range(n_bn):
-                        name = lib.opp_bn_layer_name(ctx, i).decode()
-                        C = lib.opp_bn_layer_channels(ctx, i)
-                        self.get_buffer(name + ".running_mean").mul_(1 - m).add_(stats[i, :C], alpha=m)
-                        self.get_buffer(name + ".running_var").mul_(1 - m).add_(stats[i, C:2 * C], alpha=m)
-                        self.get_buffer(name + ".num_batches_tracked").add_(1)
+    def _forward_train_impl(self, data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF):
+        self._rt["dirty"] = True                      # parameters change between training steps: always repack
+        self._rt["obj"] = None
+        lib, ctx = self._ensure_ready(device)
+        _lib.check(lib.opp_set_status_flag(ctx, None), "opp_set_status_flag")   # no sticky pointer from an eval forward
+        stream = torch.cuda.current_stream(device).cuda_stream
+        data.update({"bs": B, "q_hw_i": img.shape[2:], "q_hw_c": torch.Size([hc, wc]), "q_hw_f": torch.Size([hf, wf])})
+        img_c = self._f32(img, "query_image", device)
+        kpts = self._f32(data["keypoints3d"], "keypoints3d", device)
+        bank_f = self._f32(data["descriptors3d_db"], "descriptors3d_db", device)
+        bank_c = bank_f if "descriptors3d_coarse_db" not in data else \
+            self._f32(data["descriptors3d_coarse_db"], "descriptors3d_coarse_db", device)
+        N = int(kpts.shape[1])
+        if kpts.shape[0] != B or tuple(bank_c.shape) != (B, dC, N):
+            raise RuntimeError("bad point-cloud shapes: keypoints3d %s, coarse bank %s" % (tuple(kpts.shape), tuple(bank_c.shape)))
+        qscale = self._f32(data["query_image_scale"], "query_image_scale", device) if "query_image_scale" in data else None
+        mask = None
+        if "query_image_mask" in data:
+            if tuple(data["query_image_mask"].shape) != (B, hc, wc):
+                raise RuntimeError("query_image_mask must have the coarse resolution [B, %d, %d]" % (hc, wc))
+            mask = data["query_image_mask"].flatten(-2).to(device=device, dtype=torch.float32).contiguous()
+        pe = self._pe_tokens(hc, wc, device) if self.dense_pos_encoding is not None else None
 
-            # 2./3. coarse level per sample (:131-167)
-            conf = torch.empty((B, N, L), dtype=torch.float32, device=device)
-            i_all = torch.empty((B, N), dtype=torch.int64, device=device)
-            j_all = torch.empty((B, N), dtype=torch.int64, device=device)
-            c_all = torch.empty((B, N), dtype=torch.float32, device=device)
-            mkc = torch.empty((N, 2), dtype=torch.float32, device=device)
-            mk3 = torch.empty((N, 3), dtype=torch.float32, device=device)
-            counts = torch.zeros((B, 2), dtype=torch.int32, device=device)
-            tokens = torch.empty((L + N, dC), dtype=torch.float32, device=device)
-            wsb = max(lib.opp_transformer_workspace_bytes(ctx, 0, 1, L, N), lib.opp_coarse_match_workspace_bytes(ctx, N, L), 4096)
-            ws = self._workspace(wsb, device)
-            scale_c = float(H) / float(hc)
-            try:
-                for b in range(B):
-                    _lib.check(lib.opp_set_keypoint_extent_ref(ctx, kpts[0].data_ptr() if b > 0 else None, N if b > 0 else 0), "extent_ref")
-                    _lib.check(lib.opp_set_query_mask(ctx, mask[b].data_ptr() if mask is not None else None), "query_mask")
-                    _lib.check(lib.opp_coarse_tokens(ctx, feat_c[b].data_ptr(), pe.data_ptr() if pe is not None else None, L,
-                                                     kpts[b].data_ptr(), bank_c[b].data_ptr(), N, tokens.data_ptr(), ws.data_ptr(),
-                                                     ws.numel(), stream), "opp_coarse_tokens")
-                    _lib.check(lib.opp_transformer(ctx, 0, tokens.data_ptr(), 1, L, N, ws.data_ptr(), ws.numel(), stream), "opp_transformer")
-                    _lib.check(lib.opp_coarse_match(ctx, tokens[L:].data_ptr(), tokens.data_ptr(), N, hc, wc, kpts[b].data_ptr(), scale_c,
-                                                    qscale[b].data_ptr() if qscale is not None else None, conf[b].data_ptr(),
-                                                    i_all[b].data_ptr(), j_all[b].data_ptr(), c_all[b].data_ptr(), mkc.data_ptr(),
-                                                    mk3.data_ptr(), counts[b].data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_coarse_match")
-            finally:
-                lib.opp_set_keypoint_extent_ref(ctx, None, 0)
-                lib.opp_set_query_mask(ctx, None)
-            with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
-                ms = counts[:, 0].tolist()                                                  # one D2H sync for the batch
-            b_ids = torch.cat([torch.full((m_,), b, dtype=torch.int64, device=device) for b, m_ in enumerate(ms)])
-            i_ids = torch.cat([i_all[b, :m_] for b, m_ in enumerate(ms)])
-            j_ids = torch.cat([j_all[b, :m_] for b, m_ in enumerate(ms)])
-            mconf = torch.cat([c_all[b, :m_] for b, m_ in enumerate(ms)])
-
-            # training branch of get_coarse_match (coarse_matching.py:177-217)
-            tcfg = cfg["coarse_matching"]["train"]
-            if tcfg["train_padding"]:
-                max_train = int(B * min(N, L) * tcfg["train_coarse_percent"])
-                n_pred = int(b_ids.numel())
-                pad_min = tcfg["train_pad_num_gt_min"]
-                assert pad_min < max_train, "min-num-gt-pad should be less than num-train-matches"
-                if n_pred <= max_train - pad_min:
-                    pred_idx = torch.arange(n_pred, device=device)
-                else:
-                    pred_idx = self.train_randint(n_pred, (max_train - pad_min,), device=device)
-                spv_b, spv_i, spv_j = torch.where(data["conf_matrix_gt"])
-                assert len(spv_b) != 0
-                gt_idx = self.train_randint(len(spv_b), (max(max_train - n_pred, pad_min),), device=device)
-                b_ids = torch.cat([b_ids[pred_idx], spv_b[gt_idx]])
-                i_ids = torch.cat([i_ids[pred_idx], spv_i[gt_idx]])
-                j_ids = torch.cat([j_ids[pred_idx], spv_j[gt_idx]])
-                mconf = torch.cat([mconf[pred_idx], torch.zeros(len(gt_idx), device=device)])   # gt paddings: conf 0
-            scale_total = scale_c * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_c   # :222-225
-            mk_query = torch.stack([j_ids % wc, j_ids // wc], dim=1) * scale_total
-            mk_3d = kpts[b_ids, i_ids]
-            keep = mconf != 0
-            data.update({"conf_matrix": conf, "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0,
-                         "m_bids": b_ids[keep], "mkpts_3d_db": mk_3d[keep], "mkpts_query_c": mk_query[keep], "mconf": mconf[keep]})
-            if not cfg["fine_matching"]["enable"]:
-                data["mkpts_query_f"] = data["mkpts_query_c"]
-                return
-            # 4./5. fine level on the padded list, sample by sample (fine_preprocess.py:41-55 indexes [b_ids, j_ids])
-            data["W"] = cfg["loftr_fine"]["window_size"]
-            Mp = int(b_ids.numel())
-            assert Mp > 0, "M is always >0, when training, see coarse_matching.py"          # fine_matching.py:47
-            expec = torch.empty((Mp, 3), dtype=torch.float32, device=device)
-            mk_f = torch.empty((Mp, 2), dtype=torch.float32, device=device)
-            mk_query_f32 = mk_query.to(torch.float32).contiguous()
-            scale_f = float(H) / float(hf)
+        # 1. backbone (OnePosePlusModel.py:109-128); a frozen pretrained backbone stays in eval mode (:109-113)
+        feat_c = torch.empty((B, L, dC), dtype=torch.float32, device=device)
+        feat_f = torch.empty((B, hf * wf, dF), dtype=torch.float32, device=device)
+        frozen = bool(self.loftr_backbone_pretrained) and bool(cfg["loftr_backbone"]["pretrained_fix"])
+        if frozen:
+            nb = lib.opp_backbone_workspace_bytes(ctx, H, W)
+            ws = self._workspace(nb, device)
             for b in range(B):
-                sel = torch.nonzero(b_ids == b).flatten()
-                mb = int(sel.numel())
-                if mb == 0:
-                    continue
-                ii, jj, mc = i_ids[sel].contiguous(), j_ids[sel].contiguous(), mk_query_f32[sel].contiguous()
-                ex_b = torch.empty((mb, 3), dtype=torch.float32, device=device)
-                mf_b = torch.empty((mb, 2), dtype=torch.float32, device=device)
-                fws = self._workspace(lib.opp_fine_workspace_bytes(ctx, mb), device)
-                _lib.check(lib.opp_fine(ctx, feat_f[b].data_ptr(), hf, wf, bank_f[b].data_ptr(), N, ii.data_ptr(), jj.data_ptr(), mb,
-                                        hc, wc, mc.data_ptr(), scale_f, qscale[b].data_ptr() if qscale is not None else None,
-                                        1 if cfg["loftr_fine"]["enable"] else 0, ex_b.data_ptr(), mf_b.data_ptr(), fws.data_ptr(),
-                                        fws.numel(), stream), "opp_fine")
-                expec[sel] = ex_b
-                mk_f[sel] = mf_b           # (the shared workspace is reused by the next sample in stream order)
-            # mkpts_query_f = mkpts_query_c + (offsets)[:len(mconf)] (fine_matching.py:104-105): the predicted matches
-            # come first in the padded list, and they are the ones with mconf != 0
-            data.update({"expec_f": expec, "mkpts_query_f": mk_f[:int(keep.sum().item())]})
-            self._rt["dirty"] = True                       # running statistics moved: eval packing is stale
+                _lib.check(lib.opp_backbone(ctx, img_c[b].data_ptr(), H, W, feat_c[b].data_ptr(), feat_f[b].data_ptr(),
+                                            ws.data_ptr(), ws.numel(), stream), "opp_backbone")
+        else:
+            self._ensure_train_packed(lib, ctx, device)
+            n_bn = lib.opp_num_bn_layers(ctx)
+            stats = torch.zeros((n_bn, 512), dtype=torch.float32, device=device)
+            nb = lib.opp_backbone_train_workspace_bytes(ctx, B, H, W)
+            ws = self._workspace(nb, device)
+            _lib.check(lib.opp_backbone_train(ctx, img_c.data_ptr(), B, H, W, feat_c.data_ptr(), feat_f.data_ptr(),
+                                              stats.data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_backbone_train")
+            with torch.no_grad():                  # running statistics, like torch.nn.BatchNorm2d in train()
+                m = self.bn_momentum
+                for i in range(n_bn):
+                    name = lib.opp_bn_layer_name(ctx, i).decode()
+                    C = lib.opp_bn_layer_channels(ctx, i)
+                    self.get_buffer(name + ".running_mean").mul_(1 - m).add_(stats[i, :C], alpha=m)
+                    self.get_buffer(name + ".running_var").mul_(1 - m).add_(stats[i, C:2 * C], alpha=m)
+                    self.get_buffer(name + ".num_batches_tracked").add_(1)
+
+        # 2./3. coarse level per sample (:131-167)
+        conf = torch.empty((B, N, L), dtype=torch.float32, device=device)
+        i_all = torch.empty((B, N), dtype=torch.int64, device=device)
+        j_all = torch.empty((B, N), dtype=torch.int64, device=device)
+        c_all = torch.empty((B, N), dtype=torch.float32, device=device)
+        mkc = torch.empty((N, 2), dtype=torch.float32, device=device)
+        mk3 = torch.empty((N, 3), dtype=torch.float32, device=device)
+        counts = torch.zeros((B, 2), dtype=torch.int32, device=device)
+        tokens = torch.empty((L + N, dC), dtype=torch.float32, device=device)
+        wsb = max(lib.opp_transformer_workspace_bytes(ctx, 0, 1, L, N), lib.opp_coarse_match_workspace_bytes(ctx, N, L), 4096)
+        ws = self._workspace(wsb, device)
+        scale_c = float(H) / float(hc)
+        try:
+            for b in range(B):
+                _lib.check(lib.opp_set_keypoint_extent_ref(ctx, kpts[0].data_ptr() if b > 0 else None, N if b > 0 else 0), "extent_ref")
+                _lib.check(lib.opp_set_query_mask(ctx, mask[b].data_ptr() if mask is not None else None), "query_mask")
+                _lib.check(lib.opp_coarse_tokens(ctx, feat_c[b].data_ptr(), pe.data_ptr() if pe is not None else None, L,
+                                                 kpts[b].data_ptr(), bank_c[b].data_ptr(), N, tokens.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), stream), "opp_coarse_tokens")
+                _lib.check(lib.opp_transformer(ctx, 0, tokens.data_ptr(), 1, L, N, ws.data_ptr(), ws.numel(), stream), "opp_transformer")
+                _lib.check(lib.opp_coarse_match(ctx, tokens[L:].data_ptr(), tokens.data_ptr(), N, hc, wc, kpts[b].data_ptr(), scale_c,
+                                                qscale[b].data_ptr() if qscale is not None else None, conf[b].data_ptr(),
+                                                i_all[b].data_ptr(), j_all[b].data_ptr(), c_all[b].data_ptr(), mkc.data_ptr(),
+                                                mk3.data_ptr(), counts[b].data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_coarse_match")
+        finally:
+            lib.opp_set_keypoint_extent_ref(ctx, None, 0)
+            lib.opp_set_query_mask(ctx, None)
+        with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
+            ms = counts[:, 0].tolist()                                                  # one D2H sync for the batch
+        b_ids = torch.cat([torch.full((m_,), b, dtype=torch.int64, device=device) for b, m_ in enumerate(ms)])
+        i_ids = torch.cat([i_all[b, :m_] for b, m_ in enumerate(ms)])
+        j_ids = torch.cat([j_all[b, :m_] for b, m_ in enumerate(ms)])
+        mconf = torch.cat([c_all[b, :m_] for b, m_ in enumerate(ms)])
+
+        # training branch of get_coarse_match (coarse_matching.py:177-217)
+        tcfg = cfg["coarse_matching"]["train"]
+        if tcfg["train_padding"]:
+            max_train = int(B * min(N, L) * tcfg["train_coarse_percent"])
+            n_pred = int(b_ids.numel())
+            pad_min = tcfg["train_pad_num_gt_min"]
+            assert pad_min < max_train, "min-num-gt-pad should be less than num-train-matches"
+            if n_pred <= max_train - pad_min:
+                pred_idx = torch.arange(n_pred, device=device)
+            else:
+                pred_idx = self.train_randint(n_pred, (max_train - pad_min,), device=device)
+            spv_b, spv_i, spv_j = torch.where(data["conf_matrix_gt"])
+            assert len(spv_b) != 0
+            gt_idx = self.train_randint(len(spv_b), (max(max_train - n_pred, pad_min),), device=device)
+            b_ids = torch.cat([b_ids[pred_idx], spv_b[gt_idx]])
+            i_ids = torch.cat([i_ids[pred_idx], spv_i[gt_idx]])
+            j_ids = torch.cat([j_ids[pred_idx], spv_j[gt_idx]])
+            mconf = torch.cat([mconf[pred_idx], torch.zeros(len(gt_idx), device=device)])   # gt paddings: conf 0
+        scale_total = scale_c * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_c   # :222-225
+        mk_query = torch.stack([j_ids % wc, j_ids // wc], dim=1) * scale_total
+        mk_3d = kpts[b_ids, i_ids]
+        keep = mconf != 0
+        data.update({"conf_matrix": conf, "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0,
+                     "m_bids": b_ids[keep], "mkpts_3d_db": mk_3d[keep], "mkpts_query_c": mk_query[keep], "mconf": mconf[keep]})
+        if not cfg["fine_matching"]["enable"]:
+            data["mkpts_query_f"] = data["mkpts_query_c"]
+            return
+        # 4./5. fine level on the padded list, sample by sample (fine_preprocess.py:41-55 indexes [b_ids, j_ids])
+        data["W"] = cfg["loftr_fine"]["window_size"]
+        Mp = int(b_ids.numel())
+        assert Mp > 0, "M is always >0, when training, see coarse_matching.py"          # fine_matching.py:47
+        expec = torch.empty((Mp, 3), dtype=torch.float32, device=device)
+        mk_f = torch.empty((Mp, 2), dtype=torch.float32, device=device)
+        mk_query_f32 = mk_query.to(torch.float32).contiguous()
+        scale_f = float(H) / float(hf)
+        for b in range(B):
+            sel = torch.nonzero(b_ids == b).flatten()
+            mb = int(sel.numel())
+            if mb == 0:
+                continue
+            ii, jj, mc = i_ids[sel].contiguous(), j_ids[sel].contiguous(), mk_query_f32[sel].contiguous()
+            ex_b = torch.empty((mb, 3), dtype=torch.float32, device=device)
+            mf_b = torch.empty((mb, 2), dtype=torch.float32, device=device)
+            fws = self._workspace(lib.opp_fine_workspace_bytes(ctx, mb), device)
+            _lib.check(lib.opp_fine(ctx, feat_f[b].data_ptr(), hf, wf, bank_f[b].data_ptr(), N, ii.data_ptr(), jj.data_ptr(), mb,
+                                    hc, wc, mc.data_ptr(), scale_f, qscale[b].data_ptr() if qscale is not None else None,
+                                    1 if cfg["loftr_fine"]["enable"] else 0, ex_b.data_ptr(), mf_b.data_ptr(), fws.data_ptr(),
+                                    fws.numel(), stream), "opp_fine")
+            expec[sel] = ex_b
+            mk_f[sel] = mf_b           # (the shared workspace is reused by the next sample in stream order)
+        # mkpts_query_f = mkpts_query_c + (offsets)[:len(mconf)] (fine_matching.py:104-105): the predicted matches
+        # come first in the padded list, and they are the ones with mconf != 0
+        data.update({"expec_f": expec, "mkpts_query_f": mk_f[:int(keep.sum().item())]})
 
     def _forward_single(self, data, use_token_cache=True, sample=None):
         """One sample (B = 1) through the fused coarse call + the fine call.  `sample` = (query mask [L] floats or
         None, keypoints of batch element 0 or None) of a `_forward_batch` sample."""
+        try:
+            return self._forward_single_impl(data, use_token_cache, sample)
+        finally:
+            # the C context keeps raw pointers to per-call tensors (range-guard flag, query mask, extent reference):
+            # none of them may outlive the call (the tensors are freed / reused by the caching allocator afterwards)
+            ctx = self._rt.get("ctx")
+            if ctx:
+                lib = _lib.load()
+                lib.opp_set_status_flag(ctx, None)
+                lib.opp_set_query_mask(ctx, None)
+                lib.opp_set_keypoint_extent_ref(ctx, None, 0)
+
+    def _forward_single_impl(self, data, use_token_cache=True, sample=None):
         img = data["query_image"]
         device = img.device
         cfg = self.config

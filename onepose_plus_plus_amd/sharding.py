@@ -97,11 +97,25 @@ class GradientAverager:
         avg = GradientAverager(model)          # after model.cuda(), before the first backward
         loss.backward(); avg.average(); optimiser.step(); avg.zero()
 
-    No SyncBN, like the reference (plain nn.BatchNorm2d, backbone/resnet.py:25-26): BatchNorm statistics stay per rank.
+    No SyncBN, like the reference (plain nn.BatchNorm2d, backbone/resnet.py:25-26): BatchNorm batch statistics stay
+    per rank.  What Lightning's DistributedDataParallel does besides averaging is done here as well:
+      * construction broadcasts rank `src`'s parameters AND buffers to every rank (`sync_initial=True`), so ranks that
+        were initialised or loaded differently start from one state;
+      * `sync_buffers()` re-broadcasts the buffers (the BatchNorm running statistics) from rank `src` - DDP's default
+        `broadcast_buffers=True` does that before every forward; call it per step for the same behaviour, or before a
+        checkpoint is written by a rank other than `src`.
     """
 
-    def __init__(self, module, group=None):
+    def __init__(self, module, group=None, src=0, sync_initial=True):
         self.group = group
+        self.src = src
+        self.module = module
+        if sync_initial and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=src, group=group)
+            if hasattr(module, "repack"):
+                module.repack()                              # packed weights / cached tokens follow the new values
         self.params = [p for p in module.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -114,6 +128,16 @@ class GradientAverager:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates into the view in place
             off += n
+
+    def sync_buffers(self):
+        """broadcast the module's buffers (BatchNorm running statistics, num_batches_tracked) from rank `src`
+        (DistributedDataParallel(broadcast_buffers=True) does this before every forward)"""
+        if dist.get_world_size(self.group) > 1:
+            with torch.no_grad():
+                for b in self.module.buffers():
+                    dist.broadcast(b.data, src=self.src, group=self.group)
+            if hasattr(self.module, "repack"):
+                self.module.repack()
 
     def zero(self):
         """use instead of optimiser.zero_grad(set_to_none=True), which would detach the views"""

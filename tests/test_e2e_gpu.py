@@ -102,6 +102,43 @@ def test_train_mode_forward_vs_golden(name, precision):
     assert not torch.equal(e0["conf_matrix"], e1["conf_matrix"])
 
 
+def test_train_step_invalidates_resident_object_tokens():
+    """eval on a RESIDENT object (same keypoint / bank tensors -> the per-object token cache is hit), one training step
+    plus a parameter update that moves the keypoint-MLP weights, eval again on the SAME tensors: the second eval must
+    equal a freshly built module that loaded the updated state dict (the token cache and the folded packing follow
+    the parameters on every exit path of the train-mode forward, fine level on and off)."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    name = "train_b2_128x128_n300"
+    cfg, sd, data = H.train_setup(name)
+    gold = H.load_golden(name)
+    for fine in (True, False):
+        cfg_f = default_config(thr=cfg["coarse_matching"]["thr"], fine=fine)
+        cfg_f["coarse_matching"]["train"] = cfg["coarse_matching"]["train"]
+        model = ops.make_model(cfg_f, sd)
+        resident = {k: v[:1].cuda() for k, v in data.items() if k != "conf_matrix_gt"}
+        with torch.no_grad():
+            model.eval()
+            d0 = dict(resident)
+            model(d0)                                                       # fills the object-token cache
+            model.train()
+            model.train_randint = H.RecordedRandint([gold["randint_%d" % i] for i in range(int(gold["n_randint"]))])
+            model({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()})
+            for n_, p in model.named_parameters():                          # "optimiser" update, keypoint MLP included
+                p.mul_(1.03)
+            model.eval()
+            d1 = dict(resident)
+            model(d1)                                                       # same tensors: must NOT reuse stale tokens
+            fresh = ops.make_model(cfg_f, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+            d2 = {k: v.clone() for k, v in resident.items()}
+            fresh.eval()
+            fresh(d2)
+        torch.cuda.synchronize()
+        assert not torch.equal(d0["conf_matrix"], d1["conf_matrix"])
+        assert torch.equal(d1["conf_matrix"], d2["conf_matrix"]), "fine=%s" % fine
+        assert torch.equal(d1["i_ids"], d2["i_ids"]) and torch.equal(d1["mconf"], d2["mconf"])
+
+
 @pytest.mark.parametrize("name", ["train_b2_128x128_n300", "train_b4_64x96_n150"])
 def test_training_step_gradients(name):
     """One training step as PL_OnePosePlus.training_step runs it (lightning_model:54-81): `matcher(batch)` in train()

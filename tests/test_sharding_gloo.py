@@ -85,8 +85,14 @@ def _train_worker(rank, world, port, q):
         from onepose_plus_plus_amd.sharding import GradientAverager
         cfg = default_config()
         model = OnePosePlus_model(cfg).train()
-        broadcast_weights(model, make_state_dict(cfg, 0) if rank == 0 else None, src=0)
-        avg = GradientAverager(model)
+        model.load_state_dict(make_state_dict(cfg, rank), strict=True)     # ranks start from DIFFERENT states ...
+        avg = GradientAverager(model)                                      # ... construction broadcasts rank 0's
+        gold = make_state_dict(cfg, 0)
+        init_ok = all(torch.equal(v, gold[k]) for k, v in model.state_dict().items())
+        with torch.no_grad():                                              # per-rank BatchNorm running statistics drift
+            model.get_buffer("backbone.bn1.running_mean").add_(float(rank + 1))
+        avg.sync_buffers()                                                 # DDP broadcast_buffers=True equivalent
+        init_ok = init_ok and torch.equal(model.get_buffer("backbone.bn1.running_mean"), gold["backbone.bn1.running_mean"] + 1.0)
         names = [n for n, p in model.named_parameters() if p.requires_grad]
         opt = torch.optim.SGD(model.parameters(), lr=0.5)
 
@@ -112,7 +118,7 @@ def _train_worker(rank, world, port, q):
             refused = False
         except RuntimeError:
             refused = True
-        q.put((rank, len(names), int(avg.flat.numel()), attached_after_backward, own_ok, mean_ok, zero_ok, refused, digest))
+        q.put((rank, len(names), int(avg.flat.numel()), attached_after_backward, own_ok, mean_ok, zero_ok, refused and init_ok, digest))
     finally:
         dist.destroy_process_group()
 
