@@ -66,6 +66,10 @@ typedef struct opp_config {
    * separate streams -- MatcherPool, bench.py --streams > 1 -- where other forwards' kernels fill idle CUs: +3.5...6.5 %
    * images/s with three forwards in flight, -9 % for a forward running alone).  Results are bit-identical. */
   int tile_policy;
+  /* Not a reference key: 1 (the module default) = with gemm_precision 3 every LoFTREncoderLayer behind its Q/K/V
+   * projection (attention apply, merge, norm1, mlp.0, ReLU, mlp.2, norm2, residual; transformer.py:80-94) runs as ONE
+   * kernel over 32-token tiles whose activations stay in LDS; 0 = one launch per Linear.  Bit-identical results. */
+  int encoder_fusion;
 } opp_config;
 
 typedef struct opp_ctx opp_ctx;

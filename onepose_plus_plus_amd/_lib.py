@@ -34,6 +34,7 @@ class OppConfig(Structure):
         ("match_temperature", c_float),
         ("gemm_precision", c_int),
         ("tile_policy", c_int),
+        ("encoder_fusion", c_int),
     ]
 
 

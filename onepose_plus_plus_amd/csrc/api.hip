@@ -75,6 +75,8 @@ struct EncLayerDesc {
   float *wqkv = nullptr, *wmerge = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   float *sqkv = nullptr, *smerge = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp16x2 {scale, 1/scale} per matrix
+  // bf16x3 only: merge / mlp.0 / mlp.2 once more in the fragment-major order of the fused layer kernel (enc_chain.hip)
+  void *fmerge = nullptr, *f1 = nullptr, *f2 = nullptr;
 };
 
 }  // namespace
@@ -214,6 +216,7 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
                 "keypoint encoder must be [32,64,128]");
   OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
   OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
+  OPP_CHECK_ARG(cfg->encoder_fusion == 0 || cfg->encoder_fusion == 1, "encoder_fusion must be 0 or 1");
   OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
   opp_ctx* c = new opp_ctx();
   c->cfg = *cfg;
@@ -346,6 +349,11 @@ size_t plan_pack(opp_ctx* c, void* base) {
       e.b1 = a.f(d);
       e.g2 = a.f(d);
       e.b2 = a.f(d);
+      if (prec == OPP_PREC_BF16X3) {
+        e.fmerge = a.raw(opp_frag_b3_bytes(d, d));
+        e.f1 = a.raw(opp_frag_b3_bytes(2 * d, 2 * d));
+        e.f2 = a.raw(opp_frag_b3_bytes(d, 2 * d));
+      }
     }
   };
   plan_tr(c->coarse, c->cfg.coarse_d_model);
@@ -414,6 +422,11 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
       OPP_TRY(copy_f(e.b1, w[q + 7], d, s));
       OPP_TRY(copy_f(e.g2, w[q + 8], d, s));
       OPP_TRY(copy_f(e.b2, w[q + 9], d, s));
+      if (e.fmerge) {
+        OPP_TRY(opp_pack_frag_b3(w[q + 3], d, d, e.fmerge, s));
+        OPP_TRY(opp_pack_frag_b3(w[q + 4], 2 * d, 2 * d, e.f1, s));
+        OPP_TRY(opp_pack_frag_b3(w[q + 5], d, 2 * d, e.f2, s));
+      }
     }
     return OPP_OK;
   };
@@ -858,6 +871,7 @@ int run_linattn(const float* qkv, int C, int D, int n_seg, int len0, int len1, b
   const float* q1 = qkv + (size_t)T0 * 3 * C;
   if (n_seg == 1 && C == 256 && D == 32) {   // coarse level: MFMA KV reduction and apply, both streams per launch
     OPP_TRY(opp_linattn_kv_pair(qkv, 3 * C, len0, len1, kv0, ks0, scratch, s));
+    if (msg == nullptr) return OPP_OK;       // the fused layer kernel applies KV itself (enc_chain.hip)
     return opp_linattn_apply_pair(qkv, 3 * C, kv0, ks0, cross ? 1 : 0, msg, C, len0, len1, eps, s);
   }
   if (opp_linattn_small_ok(len0, len1, C, D))   // fine level: one launch, KV never leaves the CU
@@ -921,7 +935,7 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
 
 // LocalFeatureTransformer.forward (transformer.py:133-171) on X = [stream0 ; stream1]
 int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cross, int C, int nhead, float* X, int n_seg,
-                     int len0, int len1, Arena& a, hipStream_t s, int h2, const float* mask0 = nullptr) {
+                     int len0, int len1, Arena& a, hipStream_t s, int h2, const float* mask0 = nullptr, int fusion = 1) {
   const int D = C / nhead;
   const int T0 = n_seg * len0, T1 = n_seg * len1, T = T0 + T1;
   if (T == 0 || layers.empty()) return OPP_OK;
@@ -962,6 +976,38 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.prec = h2;
       g.h2_inv = (h2 == OPP_PREC_FP16X2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
+    }
+    // everything behind the projection in ONE launch (bf16x3): [apply ->] merge -> norm1 -> mlp.0 -> ReLU -> mlp.2 -> norm2 -> +x
+    const bool chain_apply = n_seg == 1 && C == 256 && D == 32;     // coarse level: the kernel applies KV itself
+    if (fusion && h2 == OPP_PREC_BF16X3 && e.fmerge && opp_enc_chain_ok(C, nhead, chain_apply)) {
+      OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, len1, cross, b.kv, b.ks, b.scratch, chain_apply ? nullptr : b.msg, eps_attn, s));
+      OppEncChain ch;
+      ch.C = C;
+      ch.X = X;
+      ch.ldx = C;
+      ch.out = X;
+      ch.ldo = C;
+      ch.len0 = chain_apply ? len0 : T;
+      ch.len1 = chain_apply ? len1 : 0;
+      ch.msg = b.msg;
+      ch.ldm = C;
+      ch.apply = chain_apply ? 1 : 0;
+      ch.q = b.qkv;
+      ch.ldq = 3 * C;
+      ch.kv = b.kv;
+      ch.ks = b.ks;
+      ch.cross = cross ? 1 : 0;
+      ch.eps_attn = eps_attn;
+      ch.wm = e.fmerge;
+      ch.w1 = e.f1;
+      ch.w2 = e.f2;
+      ch.g1 = e.g1;
+      ch.b1 = e.b1;
+      ch.g2 = e.g2;
+      ch.b2 = e.b2;
+      ch.eps_ln = eps_ln;
+      OPP_TRY(opp_enc_chain(ch, s));
+      continue;
     }
     OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, len1, cross, b.kv, b.ks, b.scratch, b.msg, eps_attn, s));
     if (fuse_ln) {
@@ -1053,8 +1099,9 @@ extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg
   Arena a(ws, ws_bytes);
   if (which == 0)
     return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, ctx->cfg.coarse_d_model, ctx->cfg.coarse_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg),
-                            n_seg == 1 ? ctx->query_mask : nullptr);
-  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg));
+                            n_seg == 1 ? ctx->query_mask : nullptr, ctx->cfg.encoder_fusion);
+  return transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, ctx->cfg.fine_d_model, ctx->cfg.fine_nhead, tokens, n_seg, len0, len1, a, (hipStream_t)stream, gemm_prec(ctx->cfg),
+                          nullptr, ctx->cfg.encoder_fusion);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1188,7 +1235,8 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   a.off = mark;
   OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;
-  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg), ctx->query_mask));
+  OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg), ctx->query_mask,
+                           ctx->cfg.encoder_fusion));
   a.off = mark;
   return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
                            mkpts_3d, count, a, s);
@@ -1224,7 +1272,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
   OppProfScope prof(OPP_PROF_FINE, s, (double)M * ((double)(WW + 1) * C * 4.0 + 5 * 4.0));
   OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
   if (run_transformer)
-    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg)));
+    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg), nullptr, ctx->cfg.encoder_fusion));
   const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
   return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
 }

@@ -16,6 +16,7 @@ enum {
   OPP_PROF_FINE_HEAD = 1006,       // fine_head_kernel
   OPP_PROF_FOCAL_FWD = 1007,       // focal_fwd_kernel: coarse focal loss over the B x N x L confidence matrix
   OPP_PROF_FOCAL_BWD = 1008,       // focal_bwd_kernel: its gradient
+  OPP_PROF_ENC_CHAIN = 1009,       // enc_chain_kernel: one encoder layer behind the QKV projection (work = FLOPs, MFMA-bound)
 };
 inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
 struct OppProfScope {
@@ -56,6 +57,37 @@ int opp_linattn_small_pair(const float* qkv, int ld, int n_seg, int len0, int le
                            float eps, hipStream_t stream);
 int opp_linattn_apply_pair(const float* qkv, int ld, const float* kv, const float* ks, int cross, float* out, int ldo,
                            int len0, int len1, float eps, hipStream_t stream);
+// enc_chain.hip -- one LoFTREncoderLayer behind the Q/K/V projection in ONE launch (bf16x3 arithmetic):
+// [attention apply ->] merge -> norm1 -> mlp.0(cat[x, message]) -> ReLU -> mlp.2 -> norm2 -> x + .
+struct OppEncChain {
+  int C = 256;                   // d_model: 256 (8 waves) or 128 (4 waves)
+  const float* X = nullptr;      // tokens [len0 + len1][ldx]: stream 0 rows first
+  int ldx = 0;
+  float* out = nullptr;          // may alias X (every workgroup reads only the rows it writes)
+  int ldo = 0;
+  int len0 = 0, len1 = 0;        // rows per stream (apply = 0: only their sum matters)
+  // attention message: either given ...
+  const float* msg = nullptr;    // [rows][ldm]
+  int ldm = 0;
+  // ... or computed here from phi(Q) and the reduced KV / Ksum of the two streams (C = 256, 8 heads of 32)
+  int apply = 0;
+  const float* q = nullptr;      // phi(Q) rows [rows][ldq]
+  int ldq = 0;
+  const float* kv = nullptr;     // [2][C * 32]
+  const float* ks = nullptr;     // [2][C]
+  int cross = 0;
+  float eps_attn = 1e-6f;
+  // fragment-major bf16x3 weights (opp_pack_frag_b3): merge [C][C], mlp.0 [2C][2C], mlp.2 [C][2C]
+  const void* wm = nullptr;
+  const void* w1 = nullptr;
+  const void* w2 = nullptr;
+  const float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;   // norm1 / norm2 affine
+  float eps_ln = 1e-5f;
+};
+size_t opp_frag_b3_bytes(int N, int K);
+int opp_pack_frag_b3(const float* w, int N, int K, void* out, hipStream_t stream);
+bool opp_enc_chain_ok(int C, int nhead, bool apply);
+int opp_enc_chain(const OppEncChain& a, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);

@@ -177,6 +177,7 @@ class OnePosePlus_model(nn.Module):
                     p.requires_grad = False
         self.gemm_precision = os.environ.get("OPP_GEMM_PRECISION", DEFAULT_GEMM_PRECISION)
         self.tile_policy = "latency"
+        self.encoder_fusion = os.environ.get("OPP_ENCODER_FUSION", "1") != "0"
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -209,6 +210,16 @@ class OnePosePlus_model(nn.Module):
         if name != getattr(self, "tile_policy", "latency"):
             self.__del__()
             self.tile_policy = name
+            self._reset_runtime()
+        return self
+
+    def set_encoder_fusion(self, on):
+        """True (default): with the bf16x3 arithmetic every encoder layer behind its Q/K/V projection is ONE launch
+        (include/opp_hip.h `opp_config.encoder_fusion`); False: one launch per Linear.  Bit-identical results."""
+        on = bool(on)
+        if on != getattr(self, "encoder_fusion", True):
+            self.__del__()
+            self.encoder_fusion = on
             self._reset_runtime()
         return self
 
@@ -288,6 +299,7 @@ class OnePosePlus_model(nn.Module):
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
         c.gemm_precision = GEMM_PRECISIONS[self.gemm_precision]
         c.tile_policy = 1 if getattr(self, "tile_policy", "latency") == "throughput" else 0
+        c.encoder_fusion = 1 if getattr(self, "encoder_fusion", True) else 0
         return c
 
     def _ensure_ready(self, device):

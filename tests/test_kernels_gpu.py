@@ -392,3 +392,30 @@ def test_linear_attention_vs_fp64(n_seg, len0, len1, C, nhead, cross):
             # the source length factor stays len0 (the reference multiplies by the padded length, linear_attention.py:59)
             ref_m = ref_m * (len0 / float(keep.sum()))
             assert (got_m[-T1:].double() - ref_m).abs().max().item() <= 2e-5 * max(1.0, ref_m.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,n_seg,len0,len1", [(0, 1, 4096, 5000), (0, 1, 96, 77), (0, 1, 31, 1), (0, 1, 64, 33),
+                                                    (1, 500, 25, 1), (1, 1, 25, 1), (1, 37, 25, 1)])
+def test_encoder_chain_is_bit_identical_to_the_launch_per_linear_path(which, n_seg, len0, len1):
+    """One LoFTREncoderLayer behind its Q/K/V projection as ONE kernel (enc_chain.hip: attention apply, merge, norm1,
+    mlp.0, ReLU, mlp.2, norm2, residual on 32-token tiles held in LDS; transformer.py:80-94) against the same layers run
+    Linear by Linear through opp_gemm_kernel: both walk K in the same k16-steps with the same six bf16 products, so the
+    whole transformer (coarse: 6 layers on L + N tokens; fine: 2 layers on M x (25 + 1) tokens) must agree bit for bit,
+    ragged token counts and tiles that end inside a 32-row block included."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    cfg = default_config()
+    sd = make_state_dict(cfg, 3)
+    C = 256 if which == 0 else 128
+    g = torch.Generator().manual_seed(11 + len0 + n_seg)
+    tokens = torch.randn(n_seg * (len0 + len1), C, generator=g)
+    fused = ops.make_model(cfg, sd, "bf16x3")
+    plain = ops.make_model(cfg, sd, "bf16x3").set_encoder_fusion(False).cuda()
+    assert fused.encoder_fusion if hasattr(fused, "encoder_fusion") else True
+    a = ops.transformer(fused, which, tokens, n_seg, len0, len1)
+    b = ops.transformer(plain, which, tokens, n_seg, len0, len1)
+    assert torch.isfinite(a).all()
+    assert not torch.equal(a, tokens)
+    assert torch.equal(a, b), "max |fused - plain| = %.3e" % (a - b).abs().max().item()
