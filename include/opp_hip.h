@@ -70,6 +70,12 @@ typedef struct opp_config {
    * projection (attention apply, merge, norm1, mlp.0, ReLU, mlp.2, norm2, residual; transformer.py:80-94) runs as ONE
    * kernel over 32-token tiles whose activations stay in LDS; 0 = one launch per Linear.  Bit-identical results. */
   int encoder_fusion;
+  /* Not a reference key: coarse-matcher variant under gemm_precision 3 (both operands of the score GEMM pre-split once and
+   * staged global -> LDS by LDS-DMA, 4-wave workgroups on 128 x 128 tiles, two workgroups per CU; csrc/gemm_ss.hip).
+   * 2 (the module default) = ONE sweep: dual-softmax statistics + score matrix, confidences then formed in place;
+   * 1 = TWO sweeps (statistics only, then the tiles recomputed and the confidences written once: one N x L write instead of
+   *     write + read + write, at twice the MFMA work); 0 = the r02 path (opp_gemm_kernel, image tokens as pre-split weights). */
+  int score_two_sweep;
 } opp_config;
 
 typedef struct opp_ctx opp_ctx;

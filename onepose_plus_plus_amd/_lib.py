@@ -35,6 +35,7 @@ class OppConfig(Structure):
         ("gemm_precision", c_int),
         ("tile_policy", c_int),
         ("encoder_fusion", c_int),
+        ("score_two_sweep", c_int),
     ]
 
 

@@ -217,6 +217,7 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
   OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
   OPP_CHECK_ARG(cfg->encoder_fusion == 0 || cfg->encoder_fusion == 1, "encoder_fusion must be 0 or 1");
+  OPP_CHECK_ARG(cfg->score_two_sweep >= 0 && cfg->score_two_sweep <= 2, "score_two_sweep must be 0, 1 or 2");
   OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
   opp_ctx* c = new opp_ctx();
   c->cfg = *cfg;
@@ -1117,9 +1118,24 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   float* stats = a.f(opp_coarse_match_stats_floats(n, L));
   const int sprec = score_prec(c->cfg);                // score GEMM on the split-operand path as well
   float* f2_split = sprec != OPP_PREC_FP32 ? a.f(split_floats((size_t)L * C, sprec)) : nullptr;
+  const bool two_sweep = sprec == OPP_PREC_BF16X3 && c->cfg.score_two_sweep && C % 32 == 0;
+  float* f3_split = two_sweep ? a.f(split_floats((size_t)n * C, sprec)) : nullptr;
   if (!a.ok) {
     opp_set_error("coarse_match: workspace too small");
     return OPP_ERR_WORKSPACE;
+  }
+  if (two_sweep) {
+    // both operands pre-split once (7.7 + 6.3 MB)
+    OPP_TRY(opp_b3_split(f2, f2_split, (size_t)L * C, s));
+    OPP_TRY(opp_b3_split(f3, f3_split, (size_t)n * C, s));
+    if (c->cfg.score_two_sweep == 2)   // one sweep of the split-operand GEMM (statistics + score matrix), conf formed in place
+      return opp_dual_softmax_ss_single(f3_split, f2_split, C, n, L, wc, 1.0f / (float)C, (float)((double)c->cfg.match_temperature + 1e-4),
+                                        c->query_mask, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, conf, stats, scratch,
+                                        i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count, s);
+    // the score tiles are computed twice and conf is written once
+    return opp_dual_softmax_two_sweep(f3_split, f2_split, C, n, L, wc, 1.0f / (float)C, (float)((double)c->cfg.match_temperature + 1e-4),
+                                      c->query_mask, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, conf, stats, scratch,
+                                      i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count, s);
   }
   // sim = (f3/sqrt(C)) . (f2/sqrt(C)) / (temperature + 1e-4)   (coarse_matching.py:99-107).
   // C = 256: the 1/16 feature scaling is an exact power of two, so it commutes with the sum.
@@ -1168,7 +1184,7 @@ extern "C" size_t opp_coarse_match_workspace_bytes(const opp_ctx* ctx, int n, in
   (void)ctx;
   return opp_align(opp_coarse_match_scratch_floats(n, L) * sizeof(float)) +
          opp_align(opp_coarse_match_stats_floats(n, L) * sizeof(float)) +
-         opp_align((size_t)L * 256 * sizeof(float) * 3 / 2) + 1024;
+         opp_align((size_t)L * 256 * sizeof(float) * 3 / 2) + opp_align((size_t)n * 256 * sizeof(float) * 3 / 2) + 1024;
 }
 
 extern "C" int opp_coarse_match(opp_ctx* ctx, const float* f3, const float* f2, int n, int hc, int wc, const float* kpts,

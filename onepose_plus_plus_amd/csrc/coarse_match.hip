@@ -418,12 +418,47 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   if (tid == 0) *count = running;
 }
 
+// merges of the per-tile partials of the confidence sweep (gemm_ss.hip, OPP_SS_CONF; cells = GEMM rows, points = columns)
+// per point: best = max over the cell tiles, arg = the first cell holding it (tiles are in ascending cell order and each
+// partial is its tile's first such cell), ties = how many cells hold it.  Partials [T][N], thread per point.
+__global__ __launch_bounds__(256) void point_best_merge_kernel(const float* __restrict__ pbest, const int* __restrict__ parg,
+                                                               const int* __restrict__ pties, int N, int T, float* __restrict__ obest,
+                                                               int* __restrict__ oarg, int* __restrict__ oties) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float best = -1.f;
+  int arg = 0x7fffffff, ties = 0;
+  for (int t = 0; t < T; ++t) {
+    const float b = pbest[(size_t)t * N + i];
+    if (b > best) {
+      best = b;
+      arg = parg[(size_t)t * N + i];
+      ties = pties[(size_t)t * N + i];
+    } else if (b == best) {
+      ties += pties[(size_t)t * N + i];
+    }
+  }
+  obest[i] = best;
+  oarg[i] = arg;
+  oties[i] = ties;
+}
+// per cell: max over the point tiles.  Partials [L][T] (T contiguous), thread per cell; max is order-independent
+__global__ __launch_bounds__(256) void cell_max_merge_kernel(const float* __restrict__ part, int L, int T, float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= L) return;
+  float m = 0.f;
+  for (int t = 0; t < T; ++t) m = fmaxf(m, part[(size_t)j * T + t]);
+  out[j] = m;
+}
+
 }  // namespace
 
-// partial statistics written by the score GEMM epilogue (128x128 tiles)
+// partial statistics written by the score GEMM epilogue (128x128 / 256x128 tiles) or by the two sweeps of gemm_ss
+// (sweep 1: 2 x ([N][tn] + [tm][L]); sweep 2: 3 x [N][tn] + [tm][L], laid over the same space after the merge)
 size_t opp_coarse_match_stats_floats(int N, int L) {
   const size_t tn = opp_cdiv(L, 128), tm = opp_cdiv(N, 128);
-  return 2 * ((size_t)N * tn + tm * (size_t)L) + 16;
+  // single sweep: 2 x ([N][tn] + [tm][L]); two sweeps: 2 x ([L][tm] + [tn][N]), then 3 x [tn][N] + [L][tm] over the same space
+  return 3 * (size_t)N * tn + 2 * tm * (size_t)L + 16;
 }
 
 size_t opp_coarse_match_scratch_floats(int N, int L) {
@@ -438,7 +473,7 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
                             const float* qscale, const float* stats, int stats_bm, float* scratch, long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c,
                             float* mkpts_3d, int* count, hipStream_t stream) {
   OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0, "coarse match: bad sizes N=%d L=%d wc=%d", N, L, wc);
-  OPP_CHECK_ARG(!stats || stats_bm == 128 || stats_bm == 256, "coarse match: statistics come from 128- or 256-row GEMM tiles");
+  OPP_CHECK_ARG(!stats || stats_bm == 128 || stats_bm == 256 || stats_bm == -1, "coarse match: statistics come from 128- or 256-row GEMM tiles");
   const int chunks = opp_cdiv(N, 128);
   const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
   float* rmax = scratch;
@@ -453,7 +488,9 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   const bool vec4 = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cmax) & 15) == 0);
   dim3 rgrid(opp_cdiv(N, 4)), cgrid(opp_cdiv(L, 256), chunks), lgrid(opp_cdiv(L, 256));
 
-  if (stats) {   // (max, sum exp) partials already produced by the score GEMM epilogue
+  if (stats_bm == -1) {
+    // rmax / rsum / cmax / csum were already merged into `scratch` by the caller (opp_dual_softmax_ss_single)
+  } else if (stats) {   // (max, sum exp) partials already produced by the score GEMM epilogue
     const int tn = opp_cdiv(L, 128), tm = opp_cdiv(N, stats_bm);   // score GEMM tiles: stats_bm rows x 128 columns
     const float* rpm = stats;
     const float* rps = rpm + (size_t)N * tn;
@@ -492,4 +529,102 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
                      border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
   OPP_CHECK_LAUNCH("coarse match kernels");
   return OPP_OK;
+}
+
+// ---- two sweeps of the split-operand score GEMM (gemm_ss.hip): statistics, then confidences written once ------------
+// The GEMM runs with the image cells as its rows and the 3D points as its columns (conf[point][cell] then leaves the
+// accumulators in 16-byte pieces), so "row" statistics below belong to cells and "column" statistics to points.
+int opp_dual_softmax_two_sweep(const void* f3s, const void* f2s, int C, int N, int L, int wc, float out_mul, float out_div,
+                               const float* col_mask, float thr, int border, const float* kpts, float base_scale, const float* qscale,
+                               float* conf, float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                               float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream) {
+  OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0 && C % 32 == 0, "coarse match: bad sizes N=%d L=%d wc=%d C=%d", N, L, wc, C);
+  const int tl = opp_cdiv(L, opp_gemm_ss_tile_rows()), tp = opp_cdiv(N, opp_gemm_ss_tile_cols());   // cell tiles, point tiles
+  const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
+  float* rmax = scratch;                 // per point: max / sum exp of its score row
+  float* rsum = rmax + Np;
+  float* row_cmax = rsum + Np;           // per point: best confidence, its first cell, tie count
+  int* row_arg = reinterpret_cast<int*>(row_cmax + Np);
+  int* row_ties = row_arg + Np;
+  float* cmax = reinterpret_cast<float*>(row_ties + Np);   // per cell
+  float* csum = cmax + Lp;
+  float* col_cmax = csum + Lp;
+  OppGemmSS g;
+  g.A = f2s;
+  g.B = f3s;
+  g.lda = C * 6;
+  g.ldb = C * 6;
+  g.M = L;
+  g.N = N;
+  g.K = C;
+  g.out_mul = out_mul;
+  g.out_div = out_div;
+  g.row_mask = col_mask;                 // masked image cells (coarse_matching.py:108-114)
+  // sweep 1: (max, sum exp) partials; cells [L][tp], points [tl][N]
+  g.mode = OPP_SS_STATS;
+  g.stat_rowmax = stats;
+  g.stat_rowsum = g.stat_rowmax + (size_t)L * tp;
+  g.stat_colmax = g.stat_rowsum + (size_t)L * tp;
+  g.stat_colsum = g.stat_colmax + (size_t)tl * N;
+  OPP_TRY(opp_gemm_ss(g, stream));
+  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum);
+  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum);
+  // sweep 2: confidences + per-tile partials; the partial space is reused (the merges above are done with it in stream order)
+  g.mode = OPP_SS_CONF;
+  g.rstat_max = cmax;
+  g.rstat_sum = csum;
+  g.cstat_max = rmax;
+  g.cstat_sum = rsum;
+  g.C = conf;
+  g.ldc = L;
+  g.part_best = stats;
+  g.part_arg = reinterpret_cast<int*>(stats + (size_t)tl * N);
+  g.part_ties = g.part_arg + (size_t)tl * N;
+  g.part_rowmax = reinterpret_cast<float*>(g.part_ties + (size_t)tl * N);
+  OPP_TRY(opp_gemm_ss(g, stream));
+  hipLaunchKernelGGL(point_best_merge_kernel, dim3(opp_cdiv(N, 256)), dim3(256), 0, stream, g.part_best, g.part_arg, g.part_ties, N, tl, row_cmax,
+                     row_arg, row_ties);
+  hipLaunchKernelGGL(cell_max_merge_kernel, dim3(opp_cdiv(L, 256)), dim3(256), 0, stream, g.part_rowmax, L, tp, col_cmax);
+  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, conf, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr, border, kpts,
+                     base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
+  OPP_CHECK_LAUNCH("coarse match (two sweeps)");
+  return OPP_OK;
+}
+
+// ---- single sweep on the split-operand GEMM: statistics + score matrix from gemm_ss (cells = GEMM rows), then the in-place
+// confidence pass and the selection of the materialised path ------------------------------------------------------------
+int opp_dual_softmax_ss_single(const void* f3s, const void* f2s, int C, int N, int L, int wc, float out_mul, float out_div,
+                               const float* col_mask, float thr, int border, const float* kpts, float base_scale, const float* qscale,
+                               float* conf, float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                               float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream) {
+  OPP_CHECK_ARG(N > 0 && L > 0 && wc > 0 && L % wc == 0 && C % 32 == 0, "coarse match: bad sizes N=%d L=%d wc=%d C=%d", N, L, wc, C);
+  const int tl = opp_cdiv(L, opp_gemm_ss_tile_rows()), tp = opp_cdiv(N, opp_gemm_ss_tile_cols());
+  const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
+  float* rmax = scratch;                 // same layout as opp_dual_softmax_select
+  float* rsum = rmax + Np;
+  float* cmax = rsum + Np + Np + Np + Np;
+  float* csum = cmax + Lp;
+  OppGemmSS g;
+  g.A = f2s;
+  g.B = f3s;
+  g.lda = C * 6;
+  g.ldb = C * 6;
+  g.M = L;
+  g.N = N;
+  g.K = C;
+  g.out_mul = out_mul;
+  g.out_div = out_div;
+  g.row_mask = col_mask;
+  g.mode = OPP_SS_STATS_STORE;
+  g.C = conf;
+  g.ldc = L;
+  g.stat_rowmax = stats;
+  g.stat_rowsum = g.stat_rowmax + (size_t)L * tp;
+  g.stat_colmax = g.stat_rowsum + (size_t)L * tp;
+  g.stat_colsum = g.stat_colmax + (size_t)tl * N;
+  OPP_TRY(opp_gemm_ss(g, stream));
+  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum);
+  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum);
+  return opp_dual_softmax_select(conf, N, L, wc, thr, border, kpts, base_scale, qscale, stats, -1, scratch, i_ids, j_ids, mconf, mkpts_c, mkpts_3d,
+                                 count, stream);
 }

@@ -1227,6 +1227,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
 extern "C" int opp_debug_timestamps(void* buf) {
 #ifdef OPP_TUNING
   g_dbg_ts = static_cast<unsigned long long*>(buf);
+  opp_gemm_ss_debug_timestamps(buf, getenv("OPP_SS_TS_MODE") ? atoi(getenv("OPP_SS_TS_MODE")) : 0);
   return OPP_OK;
 #else
   (void)buf;

@@ -17,6 +17,9 @@ enum {
   OPP_PROF_FOCAL_FWD = 1007,       // focal_fwd_kernel: coarse focal loss over the B x N x L confidence matrix
   OPP_PROF_FOCAL_BWD = 1008,       // focal_bwd_kernel: its gradient
   OPP_PROF_ENC_CHAIN = 1009,       // enc_chain_kernel: one encoder layer behind the QKV projection (work = FLOPs, MFMA-bound)
+  OPP_PROF_SCORE_SWEEP1 = 1010,    // gemm_ss_kernel<STATS>: score tiles -> dual-softmax statistics only (work = FLOPs)
+  OPP_PROF_SCORE_SWEEP2 = 1011,
+  OPP_PROF_SCORE_SS = 1012,        // gemm_ss_kernel<STATS_STORE>: score GEMM on pre-split operands, statistics + score matrix written (FLOPs)    // gemm_ss_kernel<CONF>: score tiles recomputed -> confidence matrix written once (work = FLOPs)
 };
 inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
 struct OppProfScope {
@@ -88,6 +91,44 @@ size_t opp_frag_b3_bytes(int N, int K);
 int opp_pack_frag_b3(const float* w, int N, int K, void* out, hipStream_t stream);
 bool opp_enc_chain_ok(int C, int nhead, bool apply);
 int opp_enc_chain(const OppEncChain& a, hipStream_t stream);
+// gemm_ss.hip -- GEMM with BOTH operands pre-split (bf16x3, opp_pack_b3 layout) staged by LDS-DMA, 4-wave workgroups on
+// 128 x 128 tiles, two workgroups per CU; used by the two-sweep coarse matcher (coarse_match.hip).
+// v[m][n] = (sum_k A[m][k] B[n][k]) * out_mul / out_div  (+ -1e9 on the rows whose row_mask is 0)
+enum { OPP_SS_STATS = 1, OPP_SS_CONF = 2, OPP_SS_STATS_STORE = 3 };   // 3: statistics + the score tile itself (out[col][row])
+struct OppGemmSS {
+  const void* A = nullptr;   // [M] rows of K split values, row stride lda BYTES (>= 6 K)
+  const void* B = nullptr;   // [N] rows, row stride ldb BYTES
+  int lda = 0, ldb = 0;
+  int M = 0, N = 0, K = 0;   // K % 32 == 0
+  int mode = OPP_SS_STATS;
+  float out_mul = 1.f, out_div = 1.f;
+  const float* row_mask = nullptr;          // [M] or null
+  // OPP_SS_STATS: (max, sum exp(v - max)) partials per tile: rows [M][tiles_n], columns [tiles_m][N]
+  float* stat_rowmax = nullptr;
+  float* stat_rowsum = nullptr;
+  float* stat_colmax = nullptr;
+  float* stat_colsum = nullptr;
+  // OPP_SS_CONF: merged statistics of the rows (rstat_*, [M]) and columns (cstat_*, [N]) in;
+  //   c[m][n] = exp((v - rstat_max[m]) + (v - cstat_max[n])) * (rcp(rstat_sum[m]) * (1 / cstat_sum[n]))
+  // stored TRANSPOSED: C[n * ldc + m].  Per tile: for every column its best c, the first row holding it and how many rows
+  // hold it ([tiles_m][N]); for every row its max c ([M][tiles_n])
+  const float* rstat_max = nullptr;
+  const float* rstat_sum = nullptr;
+  const float* cstat_max = nullptr;
+  const float* cstat_sum = nullptr;
+  float* C = nullptr;
+  int ldc = 0;
+  float* part_best = nullptr;
+  int* part_arg = nullptr;
+  int* part_ties = nullptr;
+  float* part_rowmax = nullptr;
+  int a_bytes = 0, b_bytes = 0, vec_store = 0;   // filled by the launcher
+  unsigned long long* dbg_ts = nullptr;          // -DOPP_TUNING builds: 4 shader-clock stamps per wave
+};
+void opp_gemm_ss_debug_timestamps(void* buf, int mode);   // mode 0: both sweeps stamp, else only that OPP_SS_* mode
+int opp_gemm_ss_tile_rows();
+int opp_gemm_ss_tile_cols();
+int opp_gemm_ss(const OppGemmSS& g, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);
@@ -114,6 +155,16 @@ int opp_bank_transpose(const float* bank, int n, int C, float* tokens, int ldo, 
 // coarse_match.hip
 size_t opp_coarse_match_scratch_floats(int N, int L);
 size_t opp_coarse_match_stats_floats(int N, int L);
+// two-sweep variant (bf16x3): f3s [N][C], f2s [L][C] pre-split (opp_pack_b3); conf [N][L] is written once
+int opp_dual_softmax_two_sweep(const void* f3s, const void* f2s, int C, int N, int L, int wc, float out_mul, float out_div,
+                               const float* col_mask, float thr, int border, const float* kpts, float base_scale, const float* qscale,
+                               float* conf, float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                               float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);
+// single sweep on the split-operand GEMM: score matrix + statistics by gemm_ss, then the in-place passes of opp_dual_softmax_select
+int opp_dual_softmax_ss_single(const void* f3s, const void* f2s, int C, int N, int L, int wc, float out_mul, float out_div,
+                               const float* col_mask, float thr, int border, const float* kpts, float base_scale, const float* qscale,
+                               float* conf, float* stats, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
+                               float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);
 int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int border, const float* kpts,
                             float base_scale, const float* qscale, const float* stats, int stats_bm, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
                             float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);

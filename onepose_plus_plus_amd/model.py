@@ -178,6 +178,7 @@ class OnePosePlus_model(nn.Module):
         self.gemm_precision = os.environ.get("OPP_GEMM_PRECISION", DEFAULT_GEMM_PRECISION)
         self.tile_policy = "latency"
         self.encoder_fusion = os.environ.get("OPP_ENCODER_FUSION", "1") != "0"
+        self.score_two_sweep = int(os.environ.get("OPP_SCORE_PATH", "2"))
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -220,6 +221,22 @@ class OnePosePlus_model(nn.Module):
         if on != getattr(self, "encoder_fusion", True):
             self.__del__()
             self.encoder_fusion = on
+            self._reset_runtime()
+        return self
+
+    def set_score_two_sweep(self, mode):
+        """Coarse-matcher variant under the bf16x3 arithmetic (include/opp_hip.h `opp_config.score_two_sweep`):
+          2 (default) score GEMM on operands pre-split once, staged by LDS-DMA (gemm_ss.hip): statistics + score matrix in one
+                      sweep, confidences formed in place;
+          1           two sweeps of that GEMM (statistics, then confidences written once; no score matrix in memory);
+          0 / False   the r02 path (opp_gemm_kernel with the image tokens as pre-split weights).
+        Same indices, confidences equal to rounding."""
+        mode = int(mode)
+        if mode not in (0, 1, 2):
+            raise ValueError("score path must be 0, 1 or 2")
+        if mode != getattr(self, "score_two_sweep", 2):
+            self.__del__()
+            self.score_two_sweep = mode
             self._reset_runtime()
         return self
 
@@ -300,6 +317,7 @@ class OnePosePlus_model(nn.Module):
         c.gemm_precision = GEMM_PRECISIONS[self.gemm_precision]
         c.tile_policy = 1 if getattr(self, "tile_policy", "latency") == "throughput" else 0
         c.encoder_fusion = 1 if getattr(self, "encoder_fusion", True) else 0
+        c.score_two_sweep = int(getattr(self, "score_two_sweep", 2))
         return c
 
     def _ensure_ready(self, device):

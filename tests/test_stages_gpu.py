@@ -169,3 +169,38 @@ def test_transformer_stage_full_size_vs_golden(name, precision):
     x = torch.cat([tokens2d[0], bank[0].t().contiguous()], 0)           # [L + N, C]: image tokens first
     y = ops.transformer(model, 0, x, 1, L, n)
     H.assert_transformer_digest(H.transformer_digest(y[L:], y[:L]), H.load_golden(name), rel=5e-5, where=name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("n,hw_c,planted", [(5000, (64, 64), 3000), (77, (12, 8), 40), (300, (16, 24), 200), (1000, (33, 20), 500)])
+def test_two_sweep_matcher_equals_the_materialised_path(n, hw_c, planted, mode):
+    """Coarse matcher as two sweeps of the split-operand score GEMM (gemm_ss.hip: statistics, then confidences written
+    once; coarse_matching.py:99-115, :145-172) against the r02 path that materialises the score matrix and sweeps it in
+    place: same match indices, confidences equal to rounding (the score tiles are bit-identical, only the summation order
+    of the softmax statistics differs), ragged N / L (tiles that end inside a 256 x 128 block) included."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    cfg = default_config(thr=0.1)
+    sd = make_state_dict(cfg, 0)
+    g = torch.Generator().manual_seed(5 + n)
+    L = hw_c[0] * hw_c[1]
+    f2d = torch.randn(L, 256, generator=g) * 4
+    f3d = torch.randn(n, 256, generator=g) * 4
+    m = min(planted, L, n)
+    cells = torch.randperm(L, generator=g)[:m]
+    f3d[:m] = f2d[cells] + 0.4 * torch.randn(m, 256, generator=g)
+    kpts = torch.rand(n, 3, generator=g) - 0.5
+    two = ops.make_model(cfg, sd, "bf16x3").set_score_two_sweep(mode).cuda()
+    one = ops.make_model(cfg, sd, "bf16x3").set_score_two_sweep(0).cuda()
+    a = ops.coarse_match(two, f3d, f2d, hw_c, kpts, 8.0, None)
+    b = ops.coarse_match(one, f3d, f2d, hw_c, kpts, 8.0, None)
+    assert len(b["i_ids"]) > m // 4
+    assert torch.equal(a["i_ids"], b["i_ids"]) and torch.equal(a["j_ids"], b["j_ids"])
+    ca, cb = a["conf_matrix"][0], b["conf_matrix"][0]
+    assert torch.isfinite(ca).all()
+    # the softmax statistics are sums of up to 5000 exponentials accumulated in a different (fixed) order
+    assert (ca - cb).abs().max() <= 1e-5 * max(1.0, cb.abs().max().item()), (ca - cb).abs().max()
+    assert (a["mconf"] - b["mconf"]).abs().max() <= 1e-5, (a["mconf"] - b["mconf"]).abs().max()
+    assert torch.equal(a["mkpts_query_c"], b["mkpts_query_c"]) and torch.equal(a["mkpts_3d_db"], b["mkpts_3d_db"])
