@@ -7,9 +7,9 @@
 
 Workload (BASELINE.json configs[1]): one object, 512x512 query image x 5000-point cloud,
 coarse-match only (`fine_matching.enable=False`), B=1 per forward, synthetic image/bank and
-seeded random weights (no datasets or checkpoints are available offline).  A step is one
-`OnePosePlus_model(data)` forward through the HIP path with image and descriptor banks already
-resident in HBM.  With N GPUs every rank owns a different synthetic object (per-object sharding,
+seeded random weights (no datasets or checkpoints are available offline).  A step is a fixed batch of
+IMAGES_PER_STEP = 16 B=1 `OnePosePlus_model(data)` forwards per GPU through the HIP path with image and descriptor
+banks already resident in HBM (so that the driver's `--steps 20` times >= 0.5 s, not 45 ms); `value` stays images/s.  With N GPUs every rank owns a different synthetic object (per-object sharding,
 SURVEY.md §8e): weights are broadcast once from rank 0 over RCCL, then there is no collective in
 the data path ("scaling": "weak").  Rank 0 prints ONE JSON line.
 
@@ -19,6 +19,7 @@ reference's fp32.  `--precision fp32` runs the exact-fp32 MFMA instead; the narr
 are reported as secondary legs only.
 
 Extra legs (rank 0, N=1 only):
+  (a step of the "roofline" pass below is ONE forward)
   roofline     - HIP-event timing (events recorded on the launch stream by libopp_hip.so) of every
                  launch of each profiled kernel symbol: the implicit-GEMM conv / dense / score GEMM
                  tiles (bound "mfma", algorithmic FLOPs with unpadded channel counts) and the
@@ -78,6 +79,15 @@ GEMM_SYMBOLS = [
     (0, 2, "128, 128, 2, 2, false", "coarse score GEMM + fused dual-softmax statistics, 128x128 tile, 4 waves"),
 ]
 DEPTH_OF_CFG = {10: 3, 11: 4}
+IMAGES_PER_STEP = 16
+# MFMA-bound kernels outside opp_gemm_kernel: (profile symbol, kernel name, description); work = algorithmic FLOPs
+MFMA_SYMBOLS = [
+    (1009, "enc_chain_kernel", "one encoder layer behind the QKV projection in ONE launch: attention apply, merge, norm1, mlp.0, ReLU, "
+                               "mlp.2, norm2, residual on 32-token tiles held in LDS (2 x T x (7 C^2 + 32 C) FLOP)"),
+    (1012, "gemm_ss_kernel<3>", "coarse score GEMM on operands pre-split once, LDS-DMA staged, + dual-softmax statistics + score matrix"),
+    (1010, "gemm_ss_kernel<1>", "coarse score GEMM sweep 1 (statistics only; two-sweep matcher)"),
+    (1011, "gemm_ss_kernel<2>", "coarse score GEMM sweep 2 (confidences written once; two-sweep matcher)"),
+]
 HBM_SYMBOLS = [
     (1000, "linattn_kv_mfma_kernel", "linear-attention gather: sum_s phi(K_s)^T V_s (K, V read once + chunk partials written)"),
     (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
@@ -96,8 +106,9 @@ def free_port():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; one step = --images-per-step forwards per GPU")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--images-per-step", type=int, default=IMAGES_PER_STEP)
     ap.add_argument("--n-points", type=int, default=5000)
     ap.add_argument("--hw", type=int, default=512)
     ap.add_argument("--fine", action="store_true", help="full coarse-to-fine forward instead of configs[1]")
@@ -128,6 +139,32 @@ def main():
     run(args)
 
 
+def pin_to_gpu_numa_node(torch, dev):
+    """Best effort: restrict this rank's host threads (the stream feeders) to the CPUs of the NUMA node its GPU hangs off, so
+    that an 8-rank run does not explain a non-linearity by cross-socket launches.  Returns a short description."""
+    try:
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id if hasattr(torch.cuda.get_device_properties(dev), "pci_bus_id") else None
+        dom = getattr(torch.cuda.get_device_properties(dev), "pci_domain_id", 0)
+        devid = getattr(torch.cuda.get_device_properties(dev), "pci_device_id", 0)
+        if bus is None:
+            return "unknown (no pci id)"
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bus, devid)
+        node = int(open(path).read().strip())
+        if node < 0:
+            return "numa_node -1 (single node)"
+        cpus = []
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if allowed:
+            os.sched_setaffinity(0, allowed)
+            return "numa node %d (%d cpus)" % (node, len(allowed))
+        return "numa node %d (no allowed cpu)" % node
+    except Exception as e:      # sysfs layout differs / not permitted: run unpinned
+        return "unpinned (%s)" % type(e).__name__
+
+
 def run(args):
     import torch
     from onepose_plus_plus_amd import OnePosePlus_model, default_config, _lib
@@ -142,6 +179,8 @@ def run(args):
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = pin_to_gpu_numa_node(torch, dev) if world > 1 else "not pinned (single rank)"
+    ips = max(1, args.images_per_step)
     dist = None
     if "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
@@ -201,7 +240,7 @@ def run(args):
         return d
 
     def run_steps(n, pool=None, mods=None):
-        """EXACTLY n forwards.  With several streams one host thread per stream keeps its forward in flight (the
+        """EXACTLY n forwards (callers pass steps x images_per_step).  With several streams one host thread per stream keeps its forward in flight (the
         forward's single D2H sync of the match count releases the GIL); the threads draw step indices from one
         shared counter, so no stream idles while another still has a backlog."""
         if n_streams == 1:
@@ -237,18 +276,18 @@ def run(args):
 
     # warm-up: W untimed steps on EVERY stream (packs the weights, sizes the workspaces, fills the per-object token
     # cache), then one concurrent round so that the streams, their host threads and the clocks are in steady state
-    for i in range(args.warmup):
-        for k in range(n_streams):
-            step(i, k)
+    for k in range(n_streams):            # per-stream module state: packed weights, workspaces, per-object token cache
+        step(0, k)
     torch.cuda.synchronize(dev)
-    if n_streams > 1:
-        run_steps(2 * n_streams)
+    run_steps(max(args.warmup, 1) * ips)
     lib = _lib.load()
     prof = (not args.no_roofline) and rank == 0 and world == 1
 
     barrier()
     t0 = time.perf_counter()
-    last = run_steps(args.steps)
+    last = run_steps(args.steps * ips)
+    torch.cuda.synchronize(dev)
+    own_elapsed = time.perf_counter() - t0      # this rank alone (before the closing barrier): per-rank rate below
     barrier()
     elapsed = time.perf_counter() - t0
     matches_last = int(last["mconf"].numel())
@@ -260,17 +299,19 @@ def run(args):
         devs = [None] * world
         props = torch.cuda.get_device_properties(dev)
         dist.all_gather_object(devs, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
-                                      "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()})
+                                      "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+                                      "images_per_s": round(args.steps * ips / own_elapsed, 2), "host_affinity": affinity})
         n_ranks_seen = dist.get_world_size()
     else:
         props = torch.cuda.get_device_properties(dev)
         devs = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
-                 "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}]
+                 "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+                 "images_per_s": round(args.steps * ips / own_elapsed, 2), "host_affinity": affinity}]
         n_ranks_seen = 1
 
     roof = None
     if prof:
-        roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps, 20))
+        roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps * ips, 20))
 
     legs = {}
     if rank == 0 and world == 1 and not args.no_legs:
@@ -281,24 +322,29 @@ def run(args):
         cpu = cpu_baseline(torch, cfg, make_state_dict(cfg, 0), args, make_inputs)
 
     if rank == 0:
-        total = args.steps * world
+        total = args.steps * ips * world
+        per_rank = [d["images_per_s"] for d in devs]
+        if roof is not None and legs:      # compact copies of the secondary legs inside `roofline` (driver-side parsers keep it whole)
+            roof["legs"] = compact_legs(legs)
         flops_img = 2 * (126.726e9 + 6 * (4096 + args.n_points) * 671744 + args.n_points * 4096 * 256)
         peak = MFMA_PEAK[precision]
         out = {
             "metric": "query images/sec (2D-3D match fwd) at 512x512 img x 5k pts",
             "value": round(total / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_image": round(elapsed / (args.steps * ips) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[precision],
             "data": "synthetic (seeded random image, descriptor bank and weights)",
             "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
-                                   "%d forward(s) in flight per GPU on separate HIP streams, one object per GPU; image and "
+                                   "a step = %d forwards per GPU, %d forward(s) in flight per GPU on separate HIP streams, one object per GPU; image and "
                                    "descriptor banks resident in HBM; the image-independent 3D-point tokens (keypoint-MLP "
                                    "encoding of the bank, <0.1 %% of the FLOPs) are cached per object; thr %.2f gives M = %d "
                                    "matches on these random weights (the conf matrix is still fully materialised)"
-                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", n_streams,
+                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", ips, n_streams,
                                       args.thr, matches_last),
-                       "streams_per_gpu": n_streams, "gemm_precision": precision, "tile_policy": policy,
+                       "images_per_step": ips, "streams_per_gpu": n_streams,
+                       "per_rank_images_per_s": {"min": min(per_rank), "max": max(per_rank), "sum": round(sum(per_rank), 2)}, "gemm_precision": precision, "tile_policy": policy,
                        "matches_last_step": matches_last, "object_token_cache": True,
                        "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
@@ -311,6 +357,41 @@ def run(args):
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact_legs(legs):
+    """The numbers of the secondary legs a reader wants next to the roofline, without the prose."""
+    out = {}
+    oa = legs.get("other_arithmetics") or {}
+    if oa:
+        out["other_arithmetics_images_per_s"] = {k: v.get("value") for k, v in oa.items()}
+    t = legs.get("throughput_tiles_leg")
+    if t:
+        out["throughput_tiles_images_per_s"] = t.get("value")
+    f = legs.get("fine_leg") or {}
+    if "ms_per_forward" in f:
+        out["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak")}
+    elif f:
+        out["fine"] = f
+    tr = legs.get("train_leg") or {}
+    if "step_ms" in tr:
+        out["train"] = {k: tr.get(k) for k in ("forward_ms", "step_ms", "backward_ms_in_opp_kernels", "step_samples_per_s")}
+    elif tr:
+        out["train"] = tr
+    return out
+
+
+def traffic_of(traffic, template, kernel_name=None):
+    """HBM bytes per launch of one kernel symbol from the committed PMC summary.  The summary is keyed by
+    "<template args>|grid <workgroups>" (one entry per launch shape): a symbol with ONE shape returns that entry, a
+    symbol that runs several shapes returns all of them rather than an average that fits none."""
+    key = template if template is not None else kernel_name
+    hits = {k: v for k, v in traffic.items() if k == key or k.startswith(key + "|")}
+    if not hits:
+        return None
+    if len(hits) == 1:
+        return next(iter(hits.values()))
+    return {"per_launch_shape": hits}
 
 
 def prof_run(lib, _lib, torch, dev, step, tile_cfg, kind, nsteps, pool=None, mods=None):
@@ -347,24 +428,34 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
         sym = "%s, 0, %d, %d" % (tile, DEPTH_OF_CFG.get(cfg_id, 2), spid)
         ach = fl / (ms * 1e-3) / 1e12
         meas.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(speak, 1), "unit": "TFLOP/s",
-                     "frac": round(ach / speak, 4), "traffic": traffic.get(sym),
+                     "frac": round(ach / speak, 4), "traffic": traffic_of(traffic, sym),
                      "kernel": "opp_gemm_kernel<%s> (%s, %s operands)" % (sym, what, ["fp32", "fp16x2", "bf16x3"][spid]),
-                     "symbol": sym, "measured": how, "launches": n, "launches_per_step": round(n / nsteps, 2),
-                     "avg_launch_us": round(ms * 1e3 / n, 2), "us_per_step": round(ms * 1e3 / nsteps, 1),
+                     "symbol": sym, "measured": how, "launches": n, "launches_per_forward": round(n / nsteps, 2),
+                     "avg_launch_us": round(ms * 1e3 / n, 2), "us_per_forward": round(ms * 1e3 / nsteps, 1),
                      "alg_gflop_per_launch": round(fl / n / 1e9, 3)})
+    for sid, kname, what in MFMA_SYMBOLS:
+        ms, fl, n = prof_run(lib, _lib, torch, dev, step, sid, 0, nsteps)
+        if n <= 0 or ms <= 0:
+            continue
+        ach = fl / (ms * 1e-3) / 1e12
+        meas.append({"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(ach / peak, 4), "traffic": traffic_of(traffic, None, kname),
+                     "kernel": "%s (%s, %s operands)" % (kname, what, precision), "symbol": kname, "measured": how, "launches": n,
+                     "launches_per_forward": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
+                     "us_per_forward": round(ms * 1e3 / nsteps, 1), "alg_gflop_per_launch": round(fl / n / 1e9, 3)})
     for sid, kname, what in HBM_SYMBOLS:
         ms, by, n = prof_run(lib, _lib, torch, dev, step, sid, 0, nsteps)
         if n <= 0 or ms <= 0:
             continue
         ach = by / (ms * 1e-3) / 1e9
         meas.append({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic.get(kname),
+                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic_of(traffic, None, kname),
                      "kernel": "%s (%s)" % (kname, what), "symbol": kname, "measured": how, "launches": n,
-                     "launches_per_step": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
-                     "us_per_step": round(ms * 1e3 / nsteps, 1), "alg_mbytes_per_launch": round(by / n / 1e6, 3)})
+                     "launches_per_forward": round(n / nsteps, 2), "avg_launch_us": round(ms * 1e3 / n, 2),
+                     "us_per_forward": round(ms * 1e3 / nsteps, 1), "alg_mbytes_per_launch": round(by / n / 1e6, 3)})
     if not meas:
         return None
-    meas.sort(key=lambda m: -m["us_per_step"])
+    meas.sort(key=lambda m: -m["us_per_forward"])
     roof = meas[0]
     roof["other_kernels"] = meas[1:]
     return roof
@@ -383,7 +474,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
         for k in range(n_streams):
             step(0, k)
         torch.cuda.synchronize(dev)
-        n = min(args.steps, 30)
+        n = min(args.steps * max(1, args.images_per_step), 48)
         t1 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize(dev)
@@ -401,7 +492,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
             step(0, k)
         torch.cuda.synchronize(dev)
         run_steps(2 * n_streams)
-        n = min(args.steps, 40)
+        n = min(args.steps * max(1, args.images_per_step), 96)
         t1 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize(dev)
@@ -516,7 +607,9 @@ def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):
     model = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).to(dev)
     model.load_state_dict(make_state_dict(cfg, wseed), strict=True)
     data = make_inputs(n, hw, iseed)
-    data["descriptors3d_coarse_db"] = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))["bank_c_f16"]).float()
+    gold = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    data["keypoints3d"] = torch.from_numpy(gold["keypoints3d"])               # the fixture's own object (tests/helpers.highconf_setup):
+    data["descriptors3d_coarse_db"] = torch.from_numpy(gold["bank_c_f16"]).float()   # the parity-checked input, M = 1487
     data = {k: v.to(dev) for k, v in data.items()}
 
     def fwd():

@@ -4,8 +4,8 @@ python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_
 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_driver.json 2> gpurun_out/final_bench_driver.err
 bash tools/pmc_bench.sh gpurun_out/final_pmc
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --images-per-step 1 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_fine -o fine -- python $GRAFT_REPO_ROOT/tools/fine_profile.py > $GRAFT_REPO_ROOT/gpurun_out/final_fine.log 2>&1
 cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv
 ls gpurun_out/final_s1 gpurun_out/final_s3 gpurun_out/final_fine gpurun_out/final_pmc

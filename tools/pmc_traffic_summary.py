@@ -13,10 +13,12 @@ import sys
 
 
 def load(path):
+    """(kernel name, workgroups per launch) -> counter values: one entry per LAUNCH SHAPE of a kernel symbol"""
     agg = collections.defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            wg = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])) if "Grid_Size" in r and "Workgroup_Size" in r else 0
+            agg[(r["Kernel_Name"], wg)].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -27,23 +29,26 @@ def main(d, out):
     for k in fetch:
         f = sum(fetch[k]) / len(fetch[k]) * 1024 * 2
         w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0]))) * 1024
-        rows.append((k, len(fetch[k]), f, w))
+        rows.append((k[0], len(fetch[k]), f, w, k[1]))
     rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
     with open(out, "w", newline="") as f:
         wr = csv.writer(f)
-        wr.writerow(["Kernel", "Launches", "FetchBytesPerLaunch(x2 corrected)", "WriteBytesPerLaunch"])
+        wr.writerow(["Kernel", "WorkgroupsPerLaunch", "Launches", "FetchBytesPerLaunch(x2 corrected)", "WriteBytesPerLaunch"])
         for r in rows:
-            wr.writerow([r[0], r[1], "%.0f" % r[2], "%.0f" % r[3]])
+            wr.writerow([r[0], r[4], r[1], "%.0f" % r[2], "%.0f" % r[3]])
     # per kernel symbol -> bytes per launch, read by bench.py's roofline leg: GEMM kernels are keyed by their template
     # argument string, every other kernel by its bare function name
     sym = {}
-    for k, n, fb, wb in rows:
+    for k, n, fb, wb, wg in rows:
         if "opp_gemm_kernel<" in k:
             t = k[k.find("<") + 1:k.find(">")]
+        elif "gemm_ss_kernel<" in k:
+            t = "gemm_ss_kernel<%s>" % k[k.find("<") + 1:k.find(">")]
         else:
             m = re.search(r"(?:::|^|\s)([A-Za-z_]\w*)\s*(?:<[^()]*>)?\(", k.replace("(anonymous namespace)", ""))
             t = m.group(1) if m else k
-        if t in sym:      # several instantiations of one non-GEMM kernel: keep the one with the most traffic (first)
+        t = "%s|grid %d" % (t, wg)          # one entry per launch shape (bench.py traffic_of)
+        if t in sym:
             continue
         sym[t] = {"fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                   "hbm_bytes_per_launch": round(fb + wb), "launches_sampled": n,
