@@ -214,6 +214,17 @@ int opp_dual_softmax_backward(const float* grad_conf, const float* sim, const fl
                               int B, int N, int L, float* grad_sim, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* ---- training step: backward of a bias-free nn.Linear (every Linear of loftr_coarse / loftr_fine,
+ * loftr_module/transformer.py:26-47) on the MFMA GEMM.  Y [M][N] = X [M][K] W [N][K]^T (PyTorch layouts, fp32):
+ *   grad_x [M][K] = grad_out [M][N] W            (NULL to skip; needs W)
+ *   grad_w [N][K] = grad_out^T X                 (NULL to skip; needs X; accumulate_grad_w != 0 adds to the existing values):
+ *                   a reduction over the M tokens, run as split-K with a fixed-order sum of the partials (deterministic).
+ * N, K multiples of 32; prec 0 = exact-fp32 MFMA, 2 = bf16x3 (operands carried exactly, fp32 accumulate).  Both operands
+ * are transposed / split into the workspace as needed; nothing is allocated. */
+size_t opp_linear_backward_workspace_bytes(int M, int N, int K, int prec);
+int opp_linear_backward(const float* grad_out, const float* X, const float* W, int M, int N, int K, float* grad_x, float* grad_w,
+                        int accumulate_grad_w, int prec, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

@@ -87,6 +87,8 @@ SIGNATURES = {
     "opp_focal_loss_workspace_bytes": (c_size_t, [c_size_t]),
     "opp_focal_loss_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_focal_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "opp_linear_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "opp_linear_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "opp_linear_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "opp_linear_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1339,6 +1339,13 @@ extern "C" int opp_dual_softmax_backward(const float* grad_conf, const float* si
   return opp_dual_softmax_bwd(grad_conf, sim, lse_row, lse_col, B, N, L, grad_sim, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t opp_linear_backward_workspace_bytes(int M, int N, int K, int prec) { return opp_linear_bwd_ws_bytes(M, N, K, prec); }
+
+extern "C" int opp_linear_backward(const float* grad_out, const float* X, const float* W, int M, int N, int K, float* grad_x, float* grad_w,
+                                   int accumulate_grad_w, int prec, void* ws, size_t ws_bytes, void* stream) {
+  return opp_linear_bwd(grad_out, X, W, M, N, K, grad_x, grad_w, accumulate_grad_w, prec, ws, ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int opp_conv_packed_k(int cin, int ks) { return opp_conv_k(cin, ks); }
 
 extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {

@@ -157,14 +157,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // Every tile walks K in the same order, so equal operands give bit-equal results in every
   // tile (exact ties in the confidence matrix behave like the reference's).  A per-workgroup
   // rotation of the chunk order (to spread L2 channels) was measured and gave nothing.
-  const int nk = g.K / 32;
+  // dense split-K (g.k_splits > 1, plain epilogue only): blockIdx.y walks chunks [k_first, k_first + nk) of K and writes its
+  // partial product to C + blockIdx.y * split_stride; opp_splitk_reduce sums the partials in split order
+  const int k_first = (!CONV && g.k_splits > 1) ? (int)blockIdx.y * g.k_chunks_per_split : 0;
+  const int nk = (!CONV && g.k_splits > 1) ? max(0, min(g.k_chunks_per_split, g.K / 32 - k_first)) : g.K / 32;
   const int taps = CONV ? g.ksize * g.ksize : 1;
   const int ngrp = CONV ? g.Cin / 32 : nk;            // rotation period: channel groups / chunks
   int cur_i = 0;                                      // chunks issued so far
   int cur_grp = 0;                                    // channel group (conv) or chunk index (dense)
   int cur_tap = 0, cur_ky = 0, cur_kx = 0;
-  int cur_k0 = 0;
-  unsigned cur_past = 0;
+  int cur_k0 = k_first * 32;
+  unsigned cur_past = nk > 0 ? 0u : kOob;
   // conv: byte offset of the chunk's (tap, channel group) from a_base0 and the shift that brings the
   // tap's invalid-bit to bit 31.  Per lane only in the K tail (g.tail_grp > 0: the last <= 4 real
   // channels of a Cin = 32 n + 4 input, e.g. 196, are packed 8 taps to a chunk - lane quarter kq
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       }
     } else {
       if (++cur_grp == ngrp) cur_grp = 0;
-      cur_k0 = cur_grp * 32;
+      cur_k0 = (k_first + cur_grp) * 32;
     }
   };
 
@@ -943,7 +946,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           for (int e = 0; e < 4; ++e) v[e] *= rm;
         }
       }
-      float* cp = g.C + (size_t)row * g.ldc + col;
+      float* cp = g.C + (size_t)row * g.ldc + col + ((!CONV && g.k_splits > 1) ? (size_t)blockIdx.y * g.split_stride : 0);
       if (vec_ok) {
         *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -988,7 +991,7 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
       auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH, PREC>;
       static bool attr_done = false;
       set_lds_once(k, lds, attr_done);
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+      hipLaunchKernelGGL(k, dim3(tiles, g.k_splits > 1 ? g.k_splits : 1), dim3(NT), lds, stream, g);
     }
     OPP_CHECK_LAUNCH("opp_gemm_kernel");
     return OPP_OK;
@@ -1108,6 +1111,13 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     g.a1_bytes = (unsigned)a1b;
     OPP_CHECK_ARG(g.ksplit % 32 == 0 && (g.ksplit >= g.K || g.A1), "gemm: bad ksplit");
     OPP_CHECK_ARG(g.res_mode != OPP_RES_BILINEAR2X, "gemm: bilinear residual needs conv mode");
+  }
+  if (g.k_splits > 1) {
+    OPP_CHECK_ARG(!g.conv && g.k_chunks_per_split > 0 && (long long)g.k_splits * g.k_chunks_per_split * 32 >= g.K && g.split_stride >= (size_t)g.M * g.ldc,
+                  "gemm: bad split-K description (%d splits x %d chunks for K %d)", g.k_splits, g.k_chunks_per_split, g.K);
+    OPP_CHECK_ARG(!g.bias && g.res_mode == OPP_RES_NONE && g.act == OPP_ACT_NONE && !g.ln_gamma && !g.stat_rowmax && !g.col_mask &&
+                      g.out_mul == 1.f && g.out_div == 1.f, "gemm: split-K partial products take a plain epilogue");
+    OPP_CHECK_ARG((size_t)g.k_splits * g.split_stride < (1ull << 31), "gemm: split-K partials too large for 32-bit indexing");
   }
   const bool auto_cfg = cfg < 0;
   if (cfg < 0) {

@@ -133,6 +133,11 @@ struct OppGemm {
   float ln_eps = 1e-5f;
   // algorithmic FLOPs of this launch (unpadded channel counts); 0 -> 2*M*N*K
   double alg_flops = 0.0;
+  // dense split-K (weight gradients: K = tokens): k_splits > 1 -> grid.y = k_splits, split s reduces K chunks
+  // [s * k_chunks_per_split, ...) and writes its partial product to C + s * split_stride (floats); plain epilogue only
+  int k_splits = 1;
+  int k_chunks_per_split = 0;
+  size_t split_stride = 0;
 };
 
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream);

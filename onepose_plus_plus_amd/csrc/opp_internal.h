@@ -129,6 +129,10 @@ void opp_gemm_ss_debug_timestamps(void* buf, int mode);   // mode 0: both sweeps
 int opp_gemm_ss_tile_rows();
 int opp_gemm_ss_tile_cols();
 int opp_gemm_ss(const OppGemmSS& g, hipStream_t stream);
+// linear_bwd.hip -- input / weight gradients of a bias-free Linear on the MFMA GEMM (transposed operand roles, split-K)
+size_t opp_linear_bwd_ws_bytes(int M, int N, int K, int prec);
+int opp_linear_bwd(const float* dY, const float* X, const float* W, int M, int N, int K, float* dX, float* dW, int accumulate_dw, int prec,
+                   void* ws, size_t ws_bytes, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);

@@ -4,20 +4,83 @@
 then `fine_supervision` and the loss (`losses.py:114-142`), which differentiates two outputs of the matcher:
 `conf_matrix` (focal loss over all B x N x L entries) and `expec_f` (fine L2 loss).  The FORWARD of that step runs on
 the hand-written HIP path (`OnePosePlus_model._forward_train`: BatchNorm batch statistics, training branch of
-get_coarse_match, running-statistics update) and is what every returned value comes from.  The BACKWARD is not
-hand-written yet: `TrainForward` is a `torch.autograd.Function` whose `backward` re-evaluates the same graph with
-PyTorch ops on the same device from the saved inputs -- match indices frozen to the ones the HIP forward selected,
-BatchNorm again with batch statistics but WITHOUT touching the running statistics -- and lets `torch.autograd` produce
-the parameter gradients.  This file is that differentiable restatement (functional, flat parameter dict); it is used
-for gradients only, never for forward values, and is independent of the test-side oracle.
+get_coarse_match, running-statistics update) and is what every returned value comes from.  The BACKWARD is only
+partly hand-written: `TrainForward` is a `torch.autograd.Function` whose `backward` re-evaluates the same graph on the
+same device from the saved inputs -- match indices frozen to the ones the HIP forward selected, BatchNorm again with
+batch statistics but WITHOUT touching the running statistics -- and lets `torch.autograd` walk it.  Nodes with a
+hand-written HIP backward: every Linear of the two transformers (`HipLinear`: forward, input gradient and split-K
+weight gradient on the MFMA GEMM, csrc/linear_bwd.hip), the dual softmax (`DualSoftmax`, csrc/loss.hip) and the focal
+loss (losses.py); convolutions, BatchNorm, LayerNorm and the attention einsums still differentiate through PyTorch ops.
+This file is that differentiable restatement (functional, flat parameter dict); it is used for gradients only, never
+for forward values, and is independent of the test-side oracle.
 
 Each function cites the reference code it differentiates (paths relative to src/models/OnePosePlus/).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 _EPS_BN = 1e-5
 _EPS_LN = 1e-5
+# arithmetic of the HipLinear nodes of the graph being re-evaluated (set by TrainForward.backward from the module's
+# gemm_precision: 2 = bf16x3, 0 = fp32); None = plain F.linear (CPU tensors, OPP_TRAIN_HIP_LINEAR=0)
+_HIP_LINEAR_PREC = None
+
+
+class HipLinear(torch.autograd.Function):
+    """y = x W^T for a bias-free nn.Linear (loftr_module/transformer.py:26-47) with forward AND backward on the MFMA GEMM of
+    libopp_hip.so: grad_x = grad_y W, grad_W = grad_y^T x as a split-K reduction over the tokens (include/opp_hip.h
+    `opp_linear_backward`).  x [..., K] fp32 on the device, W [N, K]; N, K multiples of 32."""
+
+    @staticmethod
+    def forward(ctx, x, w, prec):
+        from . import _lib
+        lib = _lib.load()
+        dev = x.device
+        x2 = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+        wc = w.to(torch.float32).contiguous()
+        M, K = x2.shape
+        N = wc.shape[0]
+        y = torch.empty((M, N), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            wop = wc
+            if prec == 2:
+                wop = torch.empty(N * K // 2 * 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.opp_pack_b3(wc.data_ptr(), wop.data_ptr(), N * K, stream), "opp_pack_b3")
+            _lib.check(lib.opp_linear(x2.data_ptr(), M, K, wop.data_ptr(), N, 0, y.data_ptr(), -1, prec, None, stream), "opp_linear")
+        ctx.save_for_backward(x2, wc)
+        ctx.meta = (prec, tuple(x.shape[:-1]))
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        lib = _lib.load()
+        x2, wc = ctx.saved_tensors
+        prec, lead = ctx.meta
+        dev = x2.device
+        M, K = x2.shape
+        N = wc.shape[0]
+        g2 = gy.reshape(M, N).to(torch.float32).contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty((M, K), dtype=torch.float32, device=dev) if need_x else None
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev) if need_w else None
+        nb = lib.opp_linear_backward_workspace_bytes(M, N, K, prec)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_linear_backward(g2.data_ptr(), x2.data_ptr(), wc.data_ptr(), M, N, K, dx.data_ptr() if need_x else None,
+                                               dw.data_ptr() if need_w else None, 0, prec, ws.data_ptr(), nb,
+                                               torch.cuda.current_stream(dev).cuda_stream), "opp_linear_backward")
+        return (dx.view(*lead, K) if need_x else None), dw, None
+
+
+def _linear(x, w):
+    """F.linear(x, w) of a transformer Linear; on the device with the HIP backward unless switched off"""
+    if _HIP_LINEAR_PREC is not None and x.is_cuda and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0:
+        return HipLinear.apply(x, w, _HIP_LINEAR_PREC)
+    return F.linear(x, w)
 
 
 def _bn(p, name, x):
@@ -86,12 +149,12 @@ def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loft
 def _encoder_layer(p, name, nhead, x, source, x_mask=None, source_mask=None):      # loftr_module/transformer.py:65-94
     B, _, C = x.shape
     D = C // nhead
-    q = F.linear(x, p[name + ".q_proj.weight"]).view(B, -1, nhead, D)
-    k = F.linear(source, p[name + ".k_proj.weight"]).view(B, -1, nhead, D)
-    v = F.linear(source, p[name + ".v_proj.weight"]).view(B, -1, nhead, D)
+    q = _linear(x, p[name + ".q_proj.weight"]).view(B, -1, nhead, D)
+    k = _linear(source, p[name + ".k_proj.weight"]).view(B, -1, nhead, D)
+    v = _linear(source, p[name + ".v_proj.weight"]).view(B, -1, nhead, D)
     msg = _linear_attention(q, k, v, x_mask, source_mask).reshape(B, -1, C)
-    msg = F.layer_norm(F.linear(msg, p[name + ".merge.weight"]), (C,), p[name + ".norm1.weight"], p[name + ".norm1.bias"], _EPS_LN)
-    msg = F.linear(F.relu(F.linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"])), p[name + ".mlp.2.weight"])
+    msg = F.layer_norm(_linear(msg, p[name + ".merge.weight"]), (C,), p[name + ".norm1.weight"], p[name + ".norm1.bias"], _EPS_LN)
+    msg = _linear(F.relu(_linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"])), p[name + ".mlp.2.weight"])
     return x + F.layer_norm(msg, (C,), p[name + ".norm2.weight"], p[name + ".norm2.bias"], _EPS_LN)
 
 
@@ -186,6 +249,26 @@ def differentiable_forward(p, cfg, inputs, matches, pe, bn_eval_stats=None):
     return conf, torch.cat([coords, std[:, None]], -1)
 
 
+def leaves_on_device(params):
+    return len(params) > 0 and all(p.is_cuda for p in params)
+
+
+def _pe_on(model, device):
+    """the sine table of PositionEncodingSine (67 MB) on the parameters' device, uploaded once per module, not per step"""
+    if model.dense_pos_encoding is None:
+        return None
+    pe = model.dense_pos_encoding.pe
+    if pe.device == device:
+        return pe
+    rt = model.__dict__.get("_rt")
+    key = ("pe_full", str(device))
+    if rt is not None:
+        if rt.get(key) is None:
+            rt[key] = pe.to(device)
+        return rt[key]
+    return pe.to(device)
+
+
 class TrainForward(torch.autograd.Function):
     """forward: the HIP train()-mode forward of `model` (fills `data` like the reference); returns the two outputs the
     loss differentiates.  backward: gradients of those outputs w.r.t. the parameters by torch.autograd on
@@ -211,10 +294,21 @@ class TrainForward(torch.autograd.Function):
         model = ctx.model
         params = ctx.saved_tensors
         need = [ctx.needs_input_grad[3 + i] for i in range(len(params))]
+        global _HIP_LINEAR_PREC
+        prev_prec = _HIP_LINEAR_PREC
+        if leaves_on_device(params) and os.environ.get("OPP_TRAIN_HIP_LINEAR", "1") != "0":
+            _HIP_LINEAR_PREC = {"bf16x3": 2, "fp32": 0}.get(getattr(model, "gemm_precision", "bf16x3"), 2)
+        try:
+            return TrainForward._backward_impl(ctx, model, params, need, g_conf, g_expec)
+        finally:
+            _HIP_LINEAR_PREC = prev_prec
+
+    @staticmethod
+    def _backward_impl(ctx, model, params, need, g_conf, g_expec):
         with torch.enable_grad():
             leaves = [p.detach().requires_grad_(n) for p, n in zip(params, need)]
             p = dict(zip(ctx.names, leaves))
-            pe = model.dense_pos_encoding.pe.to(leaves[0].device) if model.dense_pos_encoding is not None else None
+            pe = _pe_on(model, leaves[0].device)
             frozen = bool(model.loftr_backbone_pretrained) and bool(model.config["loftr_backbone"]["pretrained_fix"])
             stats = None
             if frozen:       # OnePosePlusModel.py:109-113: the frozen backbone runs in eval mode
