@@ -66,9 +66,11 @@ typedef struct opp_config {
    * separate streams -- MatcherPool, bench.py --streams > 1 -- where other forwards' kernels fill idle CUs: +3.5...6.5 %
    * images/s with three forwards in flight, -9 % for a forward running alone).  Results are bit-identical. */
   int tile_policy;
-  /* Not a reference key: 1 (the module default) = with gemm_precision 3 every LoFTREncoderLayer behind its Q/K/V
-   * projection (attention apply, merge, norm1, mlp.0, ReLU, mlp.2, norm2, residual; transformer.py:80-94) runs as ONE
-   * kernel over 32-token tiles whose activations stay in LDS; 0 = one launch per Linear.  Bit-identical results. */
+  /* Not a reference key: with gemm_precision 3 every LoFTREncoderLayer behind its Q/K/V projection (attention apply, merge,
+   * norm1, mlp.0, ReLU, mlp.2, norm2, residual; transformer.py:80-94) runs as ONE kernel whose activations stay in LDS:
+   * 2 (the module default) = 64-token tiles at the coarse level (one round of workgroups at 9096 tokens; csrc/enc_layer64.hip),
+   * 32-token tiles at the fine level; 1 = 32-token tiles everywhere (csrc/enc_chain.hip); 0 = one launch per Linear.
+   * Bit-identical results in all three. */
   int encoder_fusion;
   /* Not a reference key: coarse-matcher variant under gemm_precision 3 (both operands of the score GEMM pre-split once and
    * staged global -> LDS by LDS-DMA, 4-wave workgroups on 128 x 128 tiles, two workgroups per CU; csrc/gemm_ss.hip).

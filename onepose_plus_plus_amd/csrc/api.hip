@@ -216,7 +216,7 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
                 "keypoint encoder must be [32,64,128]");
   OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
   OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
-  OPP_CHECK_ARG(cfg->encoder_fusion == 0 || cfg->encoder_fusion == 1, "encoder_fusion must be 0 or 1");
+  OPP_CHECK_ARG(cfg->encoder_fusion >= 0 && cfg->encoder_fusion <= 2, "encoder_fusion must be 0, 1 or 2");
   OPP_CHECK_ARG(cfg->score_two_sweep >= 0 && cfg->score_two_sweep <= 2, "score_two_sweep must be 0, 1 or 2");
   OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
   opp_ctx* c = new opp_ctx();
@@ -1007,7 +1007,8 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       ch.g2 = e.g2;
       ch.b2 = e.b2;
       ch.eps_ln = eps_ln;
-      OPP_TRY(opp_enc_chain(ch, s));
+      if (chain_apply && fusion == 2) OPP_TRY(opp_enc_layer64(ch, s));   // 64-token tiles: one round at 9096 tokens
+      else OPP_TRY(opp_enc_chain(ch, s));
       continue;
     }
     OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, len1, cross, b.kv, b.ks, b.scratch, b.msg, eps_attn, s));

@@ -91,6 +91,8 @@ size_t opp_frag_b3_bytes(int N, int K);
 int opp_pack_frag_b3(const float* w, int N, int K, void* out, hipStream_t stream);
 bool opp_enc_chain_ok(int C, int nhead, bool apply);
 int opp_enc_chain(const OppEncChain& a, hipStream_t stream);
+// enc_layer64.hip -- the same layer on 64-token tiles (C = 256, apply fused): one round of 143 workgroups at 9096 tokens
+int opp_enc_layer64(const OppEncChain& a, hipStream_t stream);
 // gemm_ss.hip -- GEMM with BOTH operands pre-split (bf16x3, opp_pack_b3 layout) staged by LDS-DMA, 4-wave workgroups on
 // 128 x 128 tiles, two workgroups per CU; used by the two-sweep coarse matcher (coarse_match.hip).
 // v[m][n] = (sum_k A[m][k] B[n][k]) * out_mul / out_div  (+ -1e9 on the rows whose row_mask is 0)

@@ -177,7 +177,7 @@ class OnePosePlus_model(nn.Module):
                     p.requires_grad = False
         self.gemm_precision = os.environ.get("OPP_GEMM_PRECISION", DEFAULT_GEMM_PRECISION)
         self.tile_policy = "latency"
-        self.encoder_fusion = os.environ.get("OPP_ENCODER_FUSION", "1") != "0"
+        self.encoder_fusion = int(os.environ.get("OPP_ENCODER_FUSION", "2"))
         self.score_two_sweep = int(os.environ.get("OPP_SCORE_PATH", "2"))
         self._reset_runtime()
 
@@ -214,13 +214,16 @@ class OnePosePlus_model(nn.Module):
             self._reset_runtime()
         return self
 
-    def set_encoder_fusion(self, on):
-        """True (default): with the bf16x3 arithmetic every encoder layer behind its Q/K/V projection is ONE launch
-        (include/opp_hip.h `opp_config.encoder_fusion`); False: one launch per Linear.  Bit-identical results."""
-        on = bool(on)
-        if on != getattr(self, "encoder_fusion", True):
+    def set_encoder_fusion(self, level):
+        """With the bf16x3 arithmetic every encoder layer behind its Q/K/V projection is ONE launch (include/opp_hip.h
+        `opp_config.encoder_fusion`): 2 (default) = 64-token tiles at the coarse level, 1 = 32-token tiles, 0 / False =
+        one launch per Linear.  Bit-identical results."""
+        level = int(level)
+        if level not in (0, 1, 2):
+            raise ValueError("encoder_fusion must be 0, 1 or 2")
+        if level != getattr(self, "encoder_fusion", 2):
             self.__del__()
-            self.encoder_fusion = on
+            self.encoder_fusion = level
             self._reset_runtime()
         return self
 
@@ -316,7 +319,7 @@ class OnePosePlus_model(nn.Module):
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
         c.gemm_precision = GEMM_PRECISIONS[self.gemm_precision]
         c.tile_policy = 1 if getattr(self, "tile_policy", "latency") == "throughput" else 0
-        c.encoder_fusion = 1 if getattr(self, "encoder_fusion", True) else 0
+        c.encoder_fusion = int(getattr(self, "encoder_fusion", 2))
         c.score_two_sweep = int(getattr(self, "score_two_sweep", 2))
         return c
 

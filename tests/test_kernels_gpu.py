@@ -395,7 +395,7 @@ def test_linear_attention_vs_fp64(n_seg, len0, len1, C, nhead, cross):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,n_seg,len0,len1", [(0, 1, 4096, 5000), (0, 1, 96, 77), (0, 1, 31, 1), (0, 1, 64, 33),
+@pytest.mark.parametrize("which,n_seg,len0,len1", [(0, 1, 4096, 5000), (0, 1, 96, 77), (0, 1, 31, 1), (0, 1, 64, 33), (0, 1, 65, 129),
                                                     (1, 500, 25, 1), (1, 1, 25, 1), (1, 37, 25, 1)])
 def test_encoder_chain_is_bit_identical_to_the_launch_per_linear_path(which, n_seg, len0, len1):
     """One LoFTREncoderLayer behind its Q/K/V projection as ONE kernel (enc_chain.hip: attention apply, merge, norm1,
@@ -411,14 +411,14 @@ def test_encoder_chain_is_bit_identical_to_the_launch_per_linear_path(which, n_s
     C = 256 if which == 0 else 128
     g = torch.Generator().manual_seed(11 + len0 + n_seg)
     tokens = torch.randn(n_seg * (len0 + len1), C, generator=g)
-    fused = ops.make_model(cfg, sd, "bf16x3")
-    plain = ops.make_model(cfg, sd, "bf16x3").set_encoder_fusion(False).cuda()
-    assert fused.encoder_fusion if hasattr(fused, "encoder_fusion") else True
-    a = ops.transformer(fused, which, tokens, n_seg, len0, len1)
+    plain = ops.make_model(cfg, sd, "bf16x3").set_encoder_fusion(0).cuda()
     b = ops.transformer(plain, which, tokens, n_seg, len0, len1)
-    assert torch.isfinite(a).all()
-    assert not torch.equal(a, tokens)
-    assert torch.equal(a, b), "max |fused - plain| = %.3e" % (a - b).abs().max().item()
+    for level in (2, 1):       # 64-token tiles (coarse level; enc_layer64.hip) and 32-token tiles (enc_chain.hip)
+        fused = ops.make_model(cfg, sd, "bf16x3").set_encoder_fusion(level).cuda()
+        a = ops.transformer(fused, which, tokens, n_seg, len0, len1)
+        assert torch.isfinite(a).all()
+        assert not torch.equal(a, tokens)
+        assert torch.equal(a, b), "level %d: max |fused - plain| = %.3e" % (level, (a - b).abs().max().item())
 
 
 @pytest.mark.gpu

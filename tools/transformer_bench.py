@@ -23,7 +23,7 @@ def main():
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     for which, n_seg, len0, len1, C in ((0, 1, args.L, args.n, 256), (1, args.m, 25, 1, 128)):
-        for fusion in (True, False):
+        for fusion in (2, 1, 0):
             m = OnePosePlus_model(cfg).eval().set_encoder_fusion(fusion)
             m.load_state_dict(sd, strict=True)
             m = m.to(dev)
