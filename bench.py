@@ -179,7 +179,7 @@ def run(args):
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    affinity = pin_to_gpu_numa_node(torch, dev) if world > 1 else "not pinned (single rank)"
+    affinity = pin_to_gpu_numa_node(torch, dev) if (world > 1 or os.environ.get("OPP_BENCH_PIN")) else "not pinned (single rank)"
     ips = max(1, args.images_per_step)
     dist = None
     if "RANK" in os.environ:     # launched by torch.distributed.run: one rank per GPU over RCCL

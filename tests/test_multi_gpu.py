@@ -35,7 +35,7 @@ def test_bench_plain_and_torchrun_paths_agree():
     assert plain["n_gpus"] == 1 and plain["config"]["n_ranks_seen"] == 1 and plain["value"] > 0
     # the N > 1 launcher path, exercised with N = 1: RANK / WORLD_SIZE set by torch.distributed.run, RCCL process group
     port = str(29000 + os.getpid() % 2000)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPP_BENCH_PIN="1")     # also exercise the NUMA pinning of the N > 1 path
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--cpu-seconds", "0", "--no-roofline", "--no-legs", "--hw", "128", "--n-points", "300"],
@@ -44,6 +44,8 @@ def test_bench_plain_and_torchrun_paths_agree():
     tr = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert tr["config"]["n_ranks_seen"] == 1 and tr["config"]["rank_devices"][0]["rank"] == 0
     assert tr["value"] > 0 and tr["n_gpus"] == 1 and tr["scaling"] == "weak"
+    assert "host_affinity" in tr["config"]["rank_devices"][0] and tr["config"]["per_rank_images_per_s"]["sum"] > 0
+    assert tr["config"]["images_per_step"] == 16 and abs(tr["ms_per_step"] - 16 * tr["ms_per_image"]) < 1e-2 * tr["ms_per_step"]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
