@@ -826,6 +826,8 @@ int encode_points_impl(opp_ctx* c, const float* kpts, const float* bank_c, int n
 int coarse_tokens_impl(opp_ctx* c, const float* feat_c, const float* pe, int L, const float* kpts, const float* bank_c,
                        int n, const float* tokens3d_pre, float* tokens, Arena& a, hipStream_t s) {
   const int C = c->cfg.coarse_d_model;
+  if (pe && tokens3d_pre)      // the serving case: one launch for feat_c + pe and the cached point tokens
+    return opp_add_cat(feat_c, pe, (size_t)L * C, tokens3d_pre, (size_t)n * C, tokens, s);
   if (pe) {
     OPP_TRY(opp_add(feat_c, pe, tokens, (size_t)L * C, s));   // OnePosePlusModel.py:137-142
   } else if (hipMemcpyAsync(tokens, feat_c, (size_t)L * C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {

@@ -172,6 +172,19 @@ __global__ void add4_kernel(const float4* __restrict__ a, const float4* __restri
   }
 }
 
+// out[0 : n4a] = a + b ; out[n4a : n4a + n4c] = c   (token assembly: image tokens + sine encoding, then the cached point tokens)
+__global__ void add4_cat_kernel(const float4* __restrict__ a, const float4* __restrict__ b, size_t n4a, const float4* __restrict__ c,
+                                size_t n4c, float4* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4a + n4c; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < n4a) {
+      const float4 x = a[i], y = b[i];
+      out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    } else {
+      out[i] = c[i - n4a];
+    }
+  }
+}
+
 // generic 2D transpose in[R][Cc] -> out[Cc][R] through an LDS tile (used for layout conversion of
 // NCHW <-> NHWC test/interop buffers and the keypoint-MLP weights)
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
@@ -253,6 +266,16 @@ int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t st
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
   hipLaunchKernelGGL(add4_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)a, (const float4*)b, (float4*)out, n4);
   OPP_CHECK_LAUNCH("add4_kernel");
+  return OPP_OK;
+}
+
+int opp_add_cat(const float* a, const float* b, size_t na, const float* c, size_t nc, float* out, hipStream_t stream) {
+  OPP_CHECK_ARG(na % 4 == 0 && nc % 4 == 0, "add_cat: sizes %% 4 != 0");
+  const size_t n4 = (na + nc) / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(add4_cat_kernel, dim3(blocks), dim3(256), 0, stream, (const float4*)a, (const float4*)b, na / 4, (const float4*)c, nc / 4,
+                     (float4*)out);
+  OPP_CHECK_LAUNCH("add4_cat_kernel");
   return OPP_OK;
 }
 

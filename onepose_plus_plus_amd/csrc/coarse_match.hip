@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 }
 
 template <int MODE>
-__global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, int L, float* __restrict__ out) {
+__global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, int L, float* __restrict__ out, float* __restrict__ out_rcp) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= L) return;
   float acc = MODE == 0 ? -INFINITY : 0.f;
@@ -106,13 +106,14 @@ __global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, in
     else acc += v;
   }
   out[col] = acc;
+  if (MODE == 1 && out_rcp != nullptr) out_rcp[col] = __frcp_rn(acc);   // the per-column factor of conf_value(), once per column
 }
 
 // ---- merge of the per-tile (max, sum exp) partials produced by the score GEMM epilogue -----------
 // rows: part [N][T] ; cols: part [T][L] ; out max / sum with the global max as reference
 // rows: 8 lanes per row, lane u takes tiles u, u+8, ...; pairwise combine in a fixed butterfly order
 __global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
-                                                        float* __restrict__ omax, float* __restrict__ osum) {
+                                                        float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
   const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
   const int u = threadIdx.x & 7;
   float m = -INFINITY, s = 0.f;
@@ -129,11 +130,12 @@ __global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict_
   if (i < N && u == 0) {
     omax[i] = m;
     osum[i] = s;
+    if (orcp != nullptr) orcp[i] = __frcp_rn(s);
   }
 }
 // columns: block = 64 columns x 4 tile groups (group g takes tiles g, g+4, ...), combined through LDS in group order
 __global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
-                                                        float* __restrict__ omax, float* __restrict__ osum) {
+                                                        float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
@@ -150,8 +152,10 @@ __global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict_
   red[gq][c] = s;
   __syncthreads();
   if (gq == 0 && j < L) {
+    const float tot = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
     omax[j] = m;
-    osum[j] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    osum[j] = tot;
+    if (orcp != nullptr) orcp[j] = __frcp_rn(tot);
   }
 }
 // column max over `chunks` partial rows [chunks][L] (max is order-independent): 64 columns x 4 chunk groups
@@ -180,11 +184,13 @@ __global__ __launch_bounds__(256) void col_max_reduce_kernel(const float* __rest
 
 // conf = softmax_dim1 * softmax_dim2 (coarse_matching.py:115) for one entry:
 //   exp(v - cmax)/csum * exp(v - rmax)/rsum  ==  exp((v - cmax) + (v - rmax)) * (1/csum) * (1/rsum)
-// one v_exp_f32, one v_rcp_f32 and two multiplies per entry instead of two libm exps and two IEEE divisions (the
+// one v_exp_f32 and two multiplies per entry instead of two libm exps and two IEEE divisions (the
 // sweep was VALU-bound, not HBM-bound); both exponents are <= 0, relative deviation from the two-softmax form
 // ~1e-6, far inside the 1e-4 bar.  rrs = 1 / rsum of the row.
-__device__ __forceinline__ float conf_value(float v, float cm, float cs, float rm, float rrs) {
-  return __expf((v - cm) + (v - rm)) * (__frcp_rn(cs) * rrs);
+// rcs = v_rcp(csum) of the column, precomputed once per column by the statistics merge (it was one of the two
+// transcendentals per ENTRY of this VALU-bound pass)
+__device__ __forceinline__ float conf_value(float v, float cm, float rcs, float rm, float rrs) {
+  return __expf((v - cm) + (v - rm)) * (rcs * rrs);
 }
 
 // ---- conf = colsoftmax * rowsoftmax, in place; per-row max / first argmax / tie count --------
@@ -195,7 +201,7 @@ constexpr int kConfRows = 4;
 template <int VEC>
 __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N, int L,
                                                    const float* __restrict__ rmax, const float* __restrict__ rsum,
-                                                   const float* __restrict__ cmax, const float* __restrict__ csum,
+                                                   const float* __restrict__ cmax, const float* __restrict__ csum /* 1 / column sum */,
                                                    float* __restrict__ row_cmax, int* __restrict__ row_arg,
                                                    int* __restrict__ row_ties, float* __restrict__ col_part) {
   extern __shared__ unsigned colmax_bits[];
@@ -464,8 +470,8 @@ size_t opp_coarse_match_stats_floats(int N, int L) {
 size_t opp_coarse_match_scratch_floats(int N, int L) {
   const int chunks = opp_cdiv(N, 128) > opp_cdiv(N, 4 * kConfRows) ? opp_cdiv(N, 128) : opp_cdiv(N, 4 * kConfRows);
   const size_t Np = (size_t)opp_cdiv(N, 4) * 4, Lp = (size_t)opp_cdiv(L, 4) * 4;
-  // rmax, rsum, row_cmax [Np] ; row_arg, row_ties [Np] (int) ; cmax, csum, col_cmax [Lp] ; partials [chunks][L]
-  return 5 * Np + 3 * Lp + (size_t)chunks * L + 64;
+  // rmax, rsum, row_cmax [Np] ; row_arg, row_ties [Np] (int) ; cmax, csum, col_cmax, 1 / csum [Lp] ; partials [chunks][L]
+  return 5 * Np + 4 * Lp + (size_t)chunks * L + 64;
 }
 
 // S (in: similarity, out: confidence matrix) [N][L].  Outputs have capacity N.
@@ -484,7 +490,8 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   float* cmax = reinterpret_cast<float*>(row_ties + Np);
   float* csum = cmax + Lp;
   float* col_cmax = csum + Lp;
-  float* part = col_cmax + Lp;
+  float* crcp = col_cmax + Lp;          // v_rcp(csum): the per-column factor of conf_value()
+  float* part = crcp + Lp;
   const bool vec4 = (L % 4 == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0) && ((reinterpret_cast<uintptr_t>(cmax) & 15) == 0);
   dim3 rgrid(opp_cdiv(N, 4)), cgrid(opp_cdiv(L, 256), chunks), lgrid(opp_cdiv(L, 256));
 
@@ -496,15 +503,15 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
     const float* rps = rpm + (size_t)N * tn;
     const float* cpm = rps + (size_t)N * tn;
     const float* cps = cpm + (size_t)tm * L;
-    hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(N, 32)), dim3(256), 0, stream, rpm, rps, N, tn, rmax, rsum);
-    hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, cpm, cps, L, tm, cmax, csum);
+    hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(N, 32)), dim3(256), 0, stream, rpm, rps, N, tn, rmax, rsum, (float*)nullptr);
+    hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, cpm, cps, L, tm, cmax, csum, crcp);
   } else {
     if (vec4) hipLaunchKernelGGL(row_stats_kernel<4>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
     else hipLaunchKernelGGL(row_stats_kernel<1>, rgrid, dim3(256), 0, stream, S, N, L, rmax, rsum);
     hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
-    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, cmax);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, cmax, (float*)nullptr);
     hipLaunchKernelGGL(col_partial_kernel<1>, cgrid, dim3(256), 0, stream, S, N, L, 128, cmax, part);
-    hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum);
+    hipLaunchKernelGGL(col_reduce_kernel<1>, lgrid, dim3(256), 0, stream, part, chunks, L, csum, crcp);
   }
   // conf in place + per-row arg-max; the column maxima of the confidences come out of the same pass as one
   // partial row per block when the [L] LDS array fits the default dynamic-LDS limit, else from a second sweep
@@ -515,15 +522,15 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   if (vec4 && fuse_cmax && L <= 16 * 256)
   {
     OppProfScope prof(OPP_PROF_CONF, stream, (double)N * (double)L * 8.0);   // score matrix read + confidence matrix written
-    hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+    hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
   }
-  else if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
-  else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, csum, row_cmax, row_arg, row_ties, cpart);
+  else if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
+  else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
   if (fuse_cmax) {
     hipLaunchKernelGGL(col_max_reduce_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, part, cblocks, L, col_cmax);
   } else {
     hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
-    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax);
+    hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax, (float*)nullptr);
   }
   hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, S, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr,
                      border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
@@ -567,8 +574,8 @@ int opp_dual_softmax_two_sweep(const void* f3s, const void* f2s, int C, int N, i
   g.stat_colmax = g.stat_rowsum + (size_t)L * tp;
   g.stat_colsum = g.stat_colmax + (size_t)tl * N;
   OPP_TRY(opp_gemm_ss(g, stream));
-  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum);
-  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum);
+  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum, (float*)nullptr);
+  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum, (float*)nullptr);
   // sweep 2: confidences + per-tile partials; the partial space is reused (the merges above are done with it in stream order)
   g.mode = OPP_SS_CONF;
   g.rstat_max = cmax;
@@ -604,6 +611,7 @@ int opp_dual_softmax_ss_single(const void* f3s, const void* f2s, int C, int N, i
   float* rsum = rmax + Np;
   float* cmax = rsum + Np + Np + Np + Np;
   float* csum = cmax + Lp;
+  float* crcp = csum + Lp + Lp;          // behind col_cmax
   OppGemmSS g;
   g.A = f2s;
   g.B = f3s;
@@ -623,8 +631,8 @@ int opp_dual_softmax_ss_single(const void* f3s, const void* f2s, int C, int N, i
   g.stat_colmax = g.stat_rowsum + (size_t)L * tp;
   g.stat_colsum = g.stat_colmax + (size_t)tl * N;
   OPP_TRY(opp_gemm_ss(g, stream));
-  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum);
-  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum);
+  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum, crcp);
+  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum, (float*)nullptr);
   return opp_dual_softmax_select(conf, N, L, wc, thr, border, kpts, base_scale, qscale, stats, -1, scratch, i_ids, j_ids, mconf, mkpts_c, mkpts_3d,
                                  count, stream);
 }

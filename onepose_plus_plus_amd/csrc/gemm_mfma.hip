@@ -1,4 +1,4 @@
-// fp32 MFMA GEMM / implicit-GEMM convolution for gfx950.
+// MFMA GEMM / implicit-GEMM convolution for gfx950.
 //
 // Replaces, on the hot path, what the reference gets from cuDNN/cuBLAS through nn.Conv2d,
 // nn.Linear and torch.einsum:
@@ -7,21 +7,25 @@
 //   coarse score einsum src/models/OnePosePlus/utils/coarse_matching.py:102-107
 //
 // Design (MI355X-first, not a translated CUDA tiling):
-//  * v_mfma_f32_32x32x2_f32: exact fp32 (the parity budget of 1e-4 on confidences rules out
-//    bf16 operands), 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak.
-//  * Both operands are K-contiguous ("TN").  A 32-wide K chunk of a tile row is 128 B: a wave
-//    loads 8 rows x 128 B per instruction (full cache lines) and stores them to LDS as
-//    [row][36] floats (4 floats of padding).  Within a chunk the k index is permuted so that
-//    lane-half h of the wave owns k in [16h, 16h+16): every lane then pulls its MFMA operands
-//    with 4 conflict-free ds_read_b128 per 32x32 sub-tile instead of 16 scalar reads.
-//    (The MFMA sums over k, so a permutation applied to both operands is exact maths.)
-//  * Implicit im2col: the A row of an output pixel for chunk (tap, c0) is one contiguous
-//    128 B run of the NHWC input; zero rows are synthesised for the padding halo.
-//  * Double-buffered LDS, next chunk's global loads issued before the current chunk's MFMAs
-//    (register-staged prefetch), one barrier per chunk.
-//  * Epilogue fused: folded-BN bias, residual (direct or bilinear x2 align_corners=True
-//    upsample of a half-resolution NHWC tensor), ReLU / LeakyReLU / elu+1 feature map, value
-//    scaling for the linear attention, temperature scaling for the score matrix.
+//  * Three operand arithmetics behind one template (PREC), always fp32 in / fp32 accumulate / fp32 out:
+//      bf16x3 (default)  every operand carried EXACTLY as hi + mid + lo bf16, six v_mfma_f32_32x32x16_bf16 per product
+//                        (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): not narrower than fp32, 2.65x the fp32 MFMA rate;
+//                        weights pre-split at pack time (48 B per 8 k), activations split on their way to LDS;
+//      fp32              v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (157 TFLOP/s);
+//      fp16x2            opt-in, narrower than fp32: hi + lo fp16 pairs, three fp16 MFMAs per product.
+//  * Both operands are K-contiguous ("TN").  A 32-wide K chunk of a tile row is one 128 B line of fp32 activations
+//    (192 B of pre-split weights): a wave loads 8 rows per instruction with raw buffer loads (out-of-range lanes -- the
+//    padding halo of a convolution, rows past M -- read zeros from the buffer unit, so the K loop has no exec-masked control
+//    flow).  LDS rows are padded (36 / 52 floats) so that the 16 rows of a ds_read_b128 lane group fall on 16 distinct
+//    4-bank groups; within a chunk the k index is permuted so that lane half h owns one 8-k group per k16-step.
+//  * Implicit im2col: the A row of an output pixel for chunk (tap, channel group) is one contiguous run of the NHWC input.
+//    Inputs with 32 n + (1..4) channels (the 196-channel stages) pack their last channels 8 taps to a chunk.
+//  * Software pipeline: register-staged prefetch two chunks ahead, global loads and the LDS hand-over issued ONE PER MFMA
+//    SLOT, the barrier ahead of the last MFMA group so that its skew hides under MFMAs.
+//  * 8-wave tiles (two waves per SIMD) 256x128 / 128x256 / 128x128 / 64x128 / 64x256, 4-wave 64x64; XCD-aware tile order.
+//  * Epilogue through the idle operand LDS, 16 B per lane: folded-BN bias, residual (direct or bilinear x2
+//    align_corners=True), ReLU / LeakyReLU / elu+1, value scaling, LayerNorm of whole rows, dual-softmax statistics.
+//  * Dense split-K (grid.y) for the weight gradients of the training step (linear_bwd.hip).
 #include <stdlib.h>
 
 #include <mutex>
@@ -976,9 +980,11 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   // split-operand variants are built for the 64/128/256-column tiles (bf16x3: 12 x 16 B weight slots per row
   // must divide over the workgroup; its 4-wave 128x128 tile would not fit the register file)
+  // split-operand variants are instantiated for the tiles their policies can pick only (depth 2: deeper prefetch measured
+  // no better with the shorter MFMA phase; the 4-wave 128-column tiles are fp32 tiles)
   constexpr bool ok = PREC == OPP_PREC_FP32 ||
-                      ((BN == 128 || BN == 64 || BN == 256) &&
-                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64 && NT <= 512)));
+                      (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64)) && (BN == 128 || BN == 64 || BN == 256) &&
+                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64)));
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
@@ -1123,7 +1129,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   if (cfg < 0) {
     // Tile choice from the MI355X micro-bench (tools/conv_bench.py; 256 CUs x 4 SIMDs).  The
     // 196(->224)-channel stages run as two column tiles (128 + 96 real columns): measured 4-12 %
-    // faster than the dedicated 128x224 / 64x224 tiles, which stay available as explicit configs.
+    // faster than dedicated 128x224 / 64x224 tiles (removed).
     const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
     const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
     if (t0 >= 384) cfg = 0;
@@ -1209,8 +1215,6 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 0: rc = launch_cfg<128, 128, 2, 2>(g, stream); break;
     case 1: rc = launch_cfg<64, 128, 2, 2>(g, stream); break;
     case 2: rc = launch_cfg<64, 64, 2, 2>(g, stream); break;
-    case 3: rc = launch_cfg<128, 224, 4, 1>(g, stream); break;
-    case 5: rc = launch_cfg<64, 224, 2, 2>(g, stream); break;   // 4 waves: N split 128 + 96
     case 10: rc = launch_cfg<128, 128, 2, 2, 3>(g, stream); break;  // deeper global prefetch (long-K fp32 convs)
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
     case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
@@ -1218,8 +1222,6 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
-    case 27: rc = launch_cfg<256, 128, 8, 2>(g, stream); break;     // 16 waves, 32x64 per wave
-    case 28: rc = launch_cfg<128, 256, 4, 4>(g, stream); break;     // 16 waves, 32x64 per wave
     default:
 #ifdef OPP_TUNING
       rc = launch_tuning_cfg(g, cfg, stream);

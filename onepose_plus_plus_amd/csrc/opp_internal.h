@@ -147,6 +147,7 @@ int opp_h2_split(const float* in, float* out, size_t n, float* scale2, hipStream
 // bf16x3 pre-split: out holds 1.5 n floats (48 B per 8 values)
 int opp_b3_split(const float* in, float* out, size_t n, hipStream_t stream);
 int opp_add(const float* a, const float* b, float* out, size_t n, hipStream_t stream);
+int opp_add_cat(const float* a, const float* b, size_t na, const float* c, size_t nc, float* out, hipStream_t stream);
 int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStream_t stream);
 // bn_train.hip: training-mode BatchNorm (batch statistics) over an NHWC tensor [rows][ld] with C real channels:
 // out = act((y - mean_batch) * invstd_batch * gamma + beta (+ res)); stat_out [2][C] = batch mean, unbiased variance

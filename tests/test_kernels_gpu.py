@@ -28,7 +28,7 @@ def test_linear_tiles(M, K, N, cfg):
 
 @pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (77, 256, 96), (50, 64, 81),
                                    (33, 96, 7), (515, 1152, 130)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 10, 11, 20, 22, 25, 26])
+@pytest.mark.parametrize("cfg", [-1, 2, 20, 22, 25, 26])
 def test_linear_fp16x2(M, K, N, cfg):
     """fp16x2-split operands (hi + lo fp16, three fp16 MFMAs, fp32 accumulate): same error class as fp32."""
     from tests import hip_ops as ops
@@ -44,7 +44,7 @@ def test_linear_fp16x2(M, K, N, cfg):
 
 @pytest.mark.parametrize("M,K,N", [(300, 256, 768), (130, 512, 256), (64, 128, 128), (77, 256, 96), (50, 64, 81),
                                    (33, 96, 7), (515, 1152, 130), (1000, 64, 128)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 10, 20, 22, 25, 26])
+@pytest.mark.parametrize("cfg", [-1, 2, 20, 22, 25, 26])
 def test_linear_bf16x3(M, K, N, cfg):
     """bf16x3-split operands (exact hi + mid + lo bf16, six bf16 MFMAs, fp32 accumulate): the default arithmetic."""
     from tests import hip_ops as ops
@@ -126,7 +126,7 @@ def test_linear_fp16x2_weight_magnitudes(sa, sw):
         assert e_raw > 4 * e_scaled, (e_raw, e_scaled)
 
 
-@pytest.mark.parametrize("cfg", [3, 5, 10, 11, -1])
+@pytest.mark.parametrize("cfg", [10, 11, -1])
 @pytest.mark.parametrize("N", [224, 448])
 def test_linear_224_tiles(cfg, N):
     from tests import hip_ops as ops
@@ -169,7 +169,7 @@ CONV_CASES = [
 def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
     from tests import hip_ops as ops
     if cout == 196 and cfg != -1:
-        cfg = {0: 3, 2: 5, 1: 11}[cfg]
+        cfg = {0: 10, 2: 2, 1: 11}[cfg]
     g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
     x = torch.randn(1, cin, H, W, generator=g)
     w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
@@ -186,7 +186,7 @@ def test_conv_vs_torch(cin, cout, ks, stride, H, W, cfg):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 20, 22, 25, 26])
+@pytest.mark.parametrize("cfg", [-1, 2, 20, 22, 25, 26])
 def test_conv_fp16x2(cin, cout, ks, stride, H, W, cfg):
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
@@ -207,7 +207,7 @@ def test_conv_fp16x2(cin, cout, ks, stride, H, W, cfg):
 
 
 @pytest.mark.parametrize("cin,cout,ks,stride,H,W", CONV_CASES)
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 20, 22, 25, 26])
+@pytest.mark.parametrize("cfg", [-1, 2, 20, 22, 25, 26])
 def test_conv_bf16x3(cin, cout, ks, stride, H, W, cfg):
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride)
@@ -312,7 +312,7 @@ def test_results_do_not_depend_on_the_tile_shape(h2):
     makes exact confidence ties behave like the reference's."""
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(1)
-    cfgs = (25, 26, 22, 20, 2, 1) if h2 == 3 else (25, 26, 20, 22, 2, 1, 0)
+    cfgs = (25, 26, 22, 20, 2) if h2 != 0 else (25, 26, 20, 22, 2, 1, 0)
     for (M, K, N) in [(1000, 512, 512), (156, 128, 384), (4096, 64, 128)]:
         A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
         outs = [ops.linear(A, W, 1, c, h2=h2) for c in cfgs]
