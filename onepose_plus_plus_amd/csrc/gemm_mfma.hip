@@ -982,9 +982,10 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // must divide over the workgroup; its 4-wave 128x128 tile would not fit the register file)
   // split-operand variants are instantiated for the tiles their policies can pick only (depth 2: deeper prefetch measured
   // no better with the shorter MFMA phase; the 4-wave 128-column tiles are fp32 tiles)
+  // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
   constexpr bool ok = PREC == OPP_PREC_FP32 ||
-                      (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64)) && (BN == 128 || BN == 64 || BN == 256) &&
-                       (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64)));
+                      (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64) || (PREC == OPP_PREC_FP16X2 && BM == 128 && BN == 128)) &&
+                       (BN == 128 || BN == 64 || BN == 256) && (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64)));
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
