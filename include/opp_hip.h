@@ -78,6 +78,12 @@ typedef struct opp_config {
    * 1 = TWO sweeps (statistics only, then the tiles recomputed and the confidences written once: one N x L write instead of
    *     write + read + write, at twice the MFMA work); 0 = the r02 path (opp_gemm_kernel, image tokens as pre-split weights). */
   int score_two_sweep;
+  /* Not a reference key: 1 (the module default) = opp_forward_coarse runs the FPN fine branch of the backbone (layer2 / layer1
+   * lateral + output convolutions -> feat_f, needed by the fine stage only) on a side HIP stream next to the coarse level
+   * (tokens, transformer, matcher), forking after layer3_outconv and joining before it returns: the short, CU-starved launches
+   * of the coarse level and the chip-filling convolutions of the fine branch share the device.  Results are identical (same
+   * kernels, same order within each branch); the workspace holds both branches' buffers at once.  0 = one stream. */
+  int fpn_overlap;
 } opp_config;
 
 typedef struct opp_ctx opp_ctx;

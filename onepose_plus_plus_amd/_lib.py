@@ -36,6 +36,7 @@ class OppConfig(Structure):
         ("tile_policy", c_int),
         ("encoder_fusion", c_int),
         ("score_two_sweep", c_int),
+        ("fpn_overlap", c_int),
     ]
 
 

@@ -103,6 +103,9 @@ struct opp_ctx {
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
   bool train_packed = false;
+  // fine-branch overlap of opp_forward_coarse (opp_config.fpn_overlap): a side stream and two events, created on first use
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<std::string> bn_names;   // BatchNorm layers of the backbone in state-dict order (prefix, e.g. "backbone.bn1")
   std::vector<int> bn_channels;
 };
@@ -217,6 +220,7 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
   OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
   OPP_CHECK_ARG(cfg->encoder_fusion >= 0 && cfg->encoder_fusion <= 2, "encoder_fusion must be 0, 1 or 2");
+  OPP_CHECK_ARG(cfg->fpn_overlap == 0 || cfg->fpn_overlap == 1, "fpn_overlap must be 0 or 1");
   OPP_CHECK_ARG(cfg->score_two_sweep >= 0 && cfg->score_two_sweep <= 2, "score_two_sweep must be 0, 1 or 2");
   OPP_CHECK_ARG(cfg->fine_window >= 1 && cfg->fine_window * cfg->fine_window <= 64 && (cfg->fine_window & 1), "bad fine window");
   opp_ctx* c = new opp_ctx();
@@ -258,7 +262,13 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   return OPP_OK;
 }
 
-extern "C" void opp_destroy(opp_ctx* ctx) { delete ctx; }
+extern "C" void opp_destroy(opp_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+  delete ctx;
+}
 extern "C" int opp_set_query_mask(opp_ctx* ctx, const float* mask) {
   OPP_CHECK_ARG(ctx, "set_query_mask: null ctx");
   ctx->query_mask = mask;
@@ -604,56 +614,64 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
   return a.off;
 }
 
-int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s) {
+// phase 0: the whole ResNetFPN_8_2.forward; 1: stem .. layer3 + layer3_outconv (-> feat_c, the coarse map);
+// 2: the FPN fine branch (-> feat_f), which needs only x1, x2 and feat_c of phase 1 -- the coarse level does not depend on it
+int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s, int phase = 0,
+                  BackboneBufs* bufs = nullptr) {
   OPP_CHECK_ARG(c && c->packed, "backbone: weights not packed");
   OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone: H,W must be multiples of 8 (got %dx%d)", H, W);
-  BackboneBufs b;
-  plan_backbone(c, H, W, a, b);
-  if (!a.ok) {
-    opp_set_error("backbone: workspace too small");
-    return OPP_ERR_WORKSPACE;
+  BackboneBufs local;
+  BackboneBufs& b = bufs ? *bufs : local;
+  if (phase != 2) {
+    plan_backbone(c, H, W, a, b);
+    if (!a.ok) {
+      opp_set_error("backbone: workspace too small");
+      return OPP_ERR_WORKSPACE;
+    }
   }
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   const int hp = gemm_prec(c->cfg);
-  // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
-  OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
-  {
-    OppGemm g;
-    g.nonfinite = t_status_flag;
-  g.tile_policy = t_tile_policy;
-  g.nonfinite = t_status_flag;
-  g.tile_policy = t_tile_policy;
-    g.A0 = b.col;
-    g.lda0 = 64;
-    g.ksplit = 64;
-    g.W = c->stem.w;
-    g.ldw = (int)split_floats(64, hp);
-    g.M = H2 * W2;
-    g.N = c->stem.cout;
-    g.K = 64;
-    g.C = b.x0;
-    g.ldc = pad32(c->stem.cout);
-    g.n_store = pad32(c->stem.cout);
-    g.bias = c->stem.bias;
-    g.act = OPP_ACT_RELU;
-    g.prec = hp;
-    g.h2_inv = hp == OPP_PREC_FP16X2 ? c->stem.h2s + 1 : nullptr;
-    OPP_TRY(opp_gemm_launch(g, s));
+  if (phase != 2) {
+    // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
+    OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
+    {
+      OppGemm g;
+      g.nonfinite = t_status_flag;
+      g.tile_policy = t_tile_policy;
+      g.A0 = b.col;
+      g.lda0 = 64;
+      g.ksplit = 64;
+      g.W = c->stem.w;
+      g.ldw = (int)split_floats(64, hp);
+      g.M = H2 * W2;
+      g.N = c->stem.cout;
+      g.K = 64;
+      g.C = b.x0;
+      g.ldc = pad32(c->stem.cout);
+      g.n_store = pad32(c->stem.cout);
+      g.bias = c->stem.bias;
+      g.act = OPP_ACT_RELU;
+      g.prec = hp;
+      g.h2_inv = hp == OPP_PREC_FP16X2 ? c->stem.h2s + 1 : nullptr;
+      OPP_TRY(opp_gemm_launch(g, s));
+    }
+    OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s, hp));   // layer1 (:144)
+    OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s, hp));
+    OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s, hp));     // layer2 (:145)
+    OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s, hp));
+    OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s, hp));     // layer3 (:146)
+    OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s, hp));
+    // FPN (:149-157)
+    OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
   }
-  OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s, hp));   // layer1 (:144)
-  OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s, hp));
-  OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s, hp));     // layer2 (:145)
-  OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s, hp));
-  OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s, hp));     // layer3 (:146)
-  OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s, hp));
-  // FPN (:149-157)
-  OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
-  OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
-  OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
-  OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
-  OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp));
-  OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
-  OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp));
+  if (phase != 1) {
+    OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
+    OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
+    OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
+    OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp));
+    OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
+    OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp));
+  }
   return OPP_OK;
 }
 
@@ -1226,6 +1244,7 @@ extern "C" size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, 
   size_t s1 = opp_backbone_workspace_bytes(ctx, H, W);
   size_t s2 = opp_transformer_workspace_bytes(ctx, 0, 1, L, n);
   size_t s3 = opp_coarse_match_workspace_bytes(ctx, n, L);
+  if (ctx->cfg.fpn_overlap) return base + s1 + (s2 > s3 ? s2 : s3) + 2048;   // the fine branch runs beside the coarse level
   size_t m = s1 > s2 ? s1 : s2;
   m = m > s3 ? m : s3;
   return base + m + 1024;
@@ -1248,9 +1267,44 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
     opp_set_error("forward_coarse: workspace too small");
     return OPP_ERR_WORKSPACE;
   }
-  const size_t mark = a.off;
+  size_t mark = a.off;
   const int hc = H / 8, wc = W / 8, L = hc * wc, C = ctx->cfg.coarse_d_model;
-  OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
+  bool forked = false;
+  if (ctx->cfg.fpn_overlap) {
+    // The coarse level (tokens, transformer, matcher: many short launches that leave CUs idle) depends only on the
+    // coarse map; the FPN fine branch (six chip-filling convolutions, ~40 % of the backbone FLOPs) is needed by the fine
+    // stage only.  Run the fine branch on a side stream next to the coarse level: fork after layer3_outconv, join below.
+    if (!ctx->side_stream) {
+      if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        opp_set_error("forward_coarse: cannot create the side stream of the fine-branch overlap");
+        return OPP_ERR_LAUNCH;
+      }
+    }
+    BackboneBufs bufs;
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 1, &bufs));
+    mark = a.off;                                    // the backbone buffers stay alive until the join
+    (void)hipEventRecord(ctx->ev_fork, s);
+    (void)hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0);
+    const int rc = backbone_impl(ctx, image, H, W, feat_c, feat_f, a, ctx->side_stream, 2, &bufs);
+    (void)hipEventRecord(ctx->ev_join, ctx->side_stream);
+    forked = true;
+    if (rc != OPP_OK) {
+      (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
+      return rc;
+    }
+  } else {
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
+  }
+  struct Join {       // every exit path re-joins the side stream: feat_f and the workspace are the caller's again in stream order
+    opp_ctx* c;
+    hipStream_t s;
+    bool on;
+    ~Join() {
+      if (on) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+    }
+  } join{ctx, s, forked};
   a.off = mark;
   OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
   a.off = mark;

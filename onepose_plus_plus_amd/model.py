@@ -179,6 +179,7 @@ class OnePosePlus_model(nn.Module):
         self.tile_policy = "latency"
         self.encoder_fusion = int(os.environ.get("OPP_ENCODER_FUSION", "2"))
         self.score_two_sweep = int(os.environ.get("OPP_SCORE_PATH", "2"))
+        self.fpn_overlap = os.environ.get("OPP_FPN_OVERLAP", "1") != "0"
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -224,6 +225,16 @@ class OnePosePlus_model(nn.Module):
         if level != getattr(self, "encoder_fusion", 2):
             self.__del__()
             self.encoder_fusion = level
+            self._reset_runtime()
+        return self
+
+    def set_fpn_overlap(self, on):
+        """True (default): the fused coarse call runs the FPN fine branch of the backbone on a side HIP stream next to the
+        coarse level (include/opp_hip.h `opp_config.fpn_overlap`); False: one stream.  Identical results."""
+        on = bool(on)
+        if on != getattr(self, "fpn_overlap", True):
+            self.__del__()
+            self.fpn_overlap = on
             self._reset_runtime()
         return self
 
@@ -321,6 +332,7 @@ class OnePosePlus_model(nn.Module):
         c.tile_policy = 1 if getattr(self, "tile_policy", "latency") == "throughput" else 0
         c.encoder_fusion = int(getattr(self, "encoder_fusion", 2))
         c.score_two_sweep = int(getattr(self, "score_two_sweep", 2))
+        c.fpn_overlap = 1 if getattr(self, "fpn_overlap", True) else 0
         return c
 
     def _ensure_ready(self, device):

@@ -545,3 +545,22 @@ def test_precisions_agree_at_full_size():
         assert (a["conf_matrix"] - b["conf_matrix"]).abs().max() < 2e-5
         assert (a["mconf"] - b["mconf"]).abs().max() < 2e-5
         assert (a["expec_f"] - b["expec_f"]).abs().max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_fine_branch_overlap_is_transparent():
+    """`opp_config.fpn_overlap`: the FPN fine branch of the backbone on a side HIP stream next to the coarse level (fork after
+    layer3_outconv, join before opp_forward_coarse returns; backbone/resnet.py:149-157 vs OnePosePlusModel.py:131-167).  Same
+    kernels in the same order within each branch: every output, the fine-stage ones that consume feat_f included, is
+    bit-identical to the single-stream run, repeatedly and with two forwards alternating on one module."""
+    from tests import hip_ops as ops
+    name = "highconf_512x512_n3000"
+    cfg, sd, data = H.highconf_setup(name)
+    on = ops.make_model(cfg, sd, "bf16x3")
+    off = ops.make_model(cfg, sd, "bf16x3").set_fpn_overlap(False).cuda()
+    ref = ops.run_model(off, data)
+    assert len(ref["mconf"]) > 1000
+    for _ in range(3):
+        got = ops.run_model(on, data)
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f", "mkpts_query_c"):
+            assert torch.equal(got[k], ref[k]), k
