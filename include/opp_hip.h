@@ -214,6 +214,18 @@ int opp_focal_loss_forward(const float* conf, const short* conf_gt, const float*
 int opp_focal_loss_backward(const float* conf, const short* conf_gt, const float* weight, size_t n, float alpha,
                             float gamma, const float* scales, float* grad_conf, void* stream);
 
+/* The same two passes on the ground truth AS THE CALLER HOLDS IT -- gt_kind 0 = int16, 1 = fp32 (the reference's dataset emits
+ * float zeros / ones, OnePosePlus_dataset.py:174-236), 2 = uint8 / bool; values other than 0 / 1 are ignored -- and with the
+ * weight of Loss.compute_c_weight (losses.py:103-111) formed on the fly from its two factors: mask0 [B * N] (per 3D point),
+ * mask1 [B * L] (per image cell), weight[b][i][j] = mask0[b][i] * mask1[b][j]; n = B * N * L.  Pass `weight` (full array) OR
+ * both masks OR neither.  No int16 copy of conf_gt and no B x N x L weight tensor is made. */
+int opp_focal_loss_forward_ex(const float* conf, const void* conf_gt, int gt_kind, const float* weight, const float* mask0,
+                              const float* mask1, int N, int L, size_t n, float alpha, float gamma, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int opp_focal_loss_backward_ex(const float* conf, const void* conf_gt, int gt_kind, const float* weight, const float* mask0,
+                               const float* mask1, int N, int L, size_t n, float alpha, float gamma, const float* scales,
+                               float* grad_conf, void* stream);
+
 /* backward of conf = A * B, A = softmax(S, dim = points), B = softmax(S, dim = cells) (utils/coarse_matching.py:115);
  * sim, grad_conf, grad_sim [B][N][L]; lse_row [B][N] = logsumexp_j S_ij, lse_col [B][L] = logsumexp_i S_ij:
  *   grad_sim_ij = 2 conf_ij g_ij - A_ij sum_i' g_i'j conf_i'j - B_ij sum_j' g_ij' conf_ij'. */

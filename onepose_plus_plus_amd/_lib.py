@@ -90,6 +90,10 @@ SIGNATURES = {
     "opp_focal_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "opp_linear_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "opp_linear_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "opp_focal_loss_forward_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_size_t, c_float, c_float,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_focal_loss_backward_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_size_t, c_float, c_float,
+                                           c_void_p, c_void_p, c_void_p]),
     "opp_linear_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "opp_linear_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -1389,6 +1389,18 @@ extern "C" int opp_focal_loss_backward(const float* conf, const short* conf_gt, 
   return opp_focal_loss_bwd(conf, conf_gt, weight, n, alpha, gamma, scales, grad_conf, (hipStream_t)stream);
 }
 
+extern "C" int opp_focal_loss_forward_ex(const float* conf, const void* conf_gt, int gt_kind, const float* weight, const float* mask0,
+                                         const float* mask1, int N, int L, size_t n, float alpha, float gamma, double* sums, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  return opp_focal_loss_fwd_ex(conf, conf_gt, gt_kind, weight, mask0, mask1, N, L, n, alpha, gamma, sums, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int opp_focal_loss_backward_ex(const float* conf, const void* conf_gt, int gt_kind, const float* weight, const float* mask0,
+                                          const float* mask1, int N, int L, size_t n, float alpha, float gamma, const float* scales,
+                                          float* grad_conf, void* stream) {
+  return opp_focal_loss_bwd_ex(conf, conf_gt, gt_kind, weight, mask0, mask1, N, L, n, alpha, gamma, scales, grad_conf, (hipStream_t)stream);
+}
+
 extern "C" size_t opp_dual_softmax_backward_workspace_bytes(int B, int N, int L) { return opp_dual_softmax_bwd_ws_bytes(B, N, L); }
 
 extern "C" int opp_dual_softmax_backward(const float* grad_conf, const float* sim, const float* lse_row, const float* lse_col, int B,

@@ -38,26 +38,74 @@ __device__ __forceinline__ void focal_add(float conf, int gt, float w, float alp
   }
 }
 
-__global__ __launch_bounds__(kLossThreads) void focal_fwd_kernel(const float* __restrict__ conf, const short* __restrict__ gt,
-                                                                 const float* __restrict__ weight, size_t n, float alpha,
-                                                                 float gamma, double* __restrict__ part) {
+// ground truth as the data loader / caller holds it: int16 (the reference casts to it), fp32 (the reference's dataset emits
+// float zeros and ones) or 8-bit (bool); values other than 0 / 1 are ignored like the reference's `== 1` / `== 0` masks.
+// The optional per-entry weight is either a full array or -- Loss.compute_c_weight, losses.py:103-111 -- the outer product
+// mask0[b][i] * mask1[b][j], formed on the fly from the two vectors (no B x N x L weight tensor is ever materialised).
+template <typename GT>
+struct GtVec;
+template <>
+struct GtVec<short> {
+  typedef short4 v4;
+  static __device__ __forceinline__ int cls(short g) { return g == 1 ? 1 : (g == 0 ? 0 : -1); }
+};
+template <>
+struct GtVec<float> {
+  typedef float4 v4;
+  static __device__ __forceinline__ int cls(float g) { return g == 1.0f ? 1 : (g == 0.0f ? 0 : -1); }
+};
+template <>
+struct GtVec<unsigned char> {
+  typedef uchar4 v4;
+  static __device__ __forceinline__ int cls(unsigned char g) { return g == 1 ? 1 : (g == 0 ? 0 : -1); }
+};
+struct FocalW {          // weight source: w (full array) | m0 / m1 (outer product; N rows per sample, L columns) | none
+  const float* w;
+  const float* m0;
+  const float* m1;
+  int N, L;
+};
+__device__ __forceinline__ float4 focal_w4(const FocalW& fw, size_t i4) {   // weights of entries 4 i4 .. 4 i4 + 3 (L % 4 == 0 if masks)
+  if (fw.w) return reinterpret_cast<const float4*>(fw.w)[i4];
+  if (fw.m0) {
+    const size_t i = i4 << 2;
+    const size_t row = i / (size_t)fw.L;
+    const int l = (int)(i - row * fw.L);
+    const size_t bsmp = row / (size_t)fw.N;
+    const float a = fw.m0[row];
+    const float4 c = *reinterpret_cast<const float4*>(fw.m1 + bsmp * fw.L + l);
+    return make_float4(a * c.x, a * c.y, a * c.z, a * c.w);
+  }
+  return make_float4(1.f, 1.f, 1.f, 1.f);
+}
+__device__ __forceinline__ float focal_w1(const FocalW& fw, size_t i) {
+  if (fw.w) return fw.w[i];
+  if (fw.m0) {
+    const size_t row = i / (size_t)fw.L;
+    const int l = (int)(i - row * fw.L);
+    return fw.m0[row] * fw.m1[(row / (size_t)fw.N) * fw.L + l];
+  }
+  return 1.f;
+}
+
+template <typename GT>
+__global__ __launch_bounds__(kLossThreads) void focal_fwd_kernel(const float* __restrict__ conf, const GT* __restrict__ gt, const FocalW fw,
+                                                                 size_t n, int vec_ok, float alpha, float gamma, double* __restrict__ part) {
   Acc a;
-  const size_t n4 = n >> 2;
+  const size_t n4 = vec_ok ? (n >> 2) : 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 c = reinterpret_cast<const float4*>(conf)[i];
-    const short4 g = reinterpret_cast<const short4*>(gt)[i];
-    float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (weight) w = reinterpret_cast<const float4*>(weight)[i];
-    focal_add(c.x, g.x, w.x, alpha, gamma, a);
-    focal_add(c.y, g.y, w.y, alpha, gamma, a);
-    focal_add(c.z, g.z, w.z, alpha, gamma, a);
-    focal_add(c.w, g.w, w.w, alpha, gamma, a);
+    const typename GtVec<GT>::v4 g = reinterpret_cast<const typename GtVec<GT>::v4*>(gt)[i];
+    const float4 w = focal_w4(fw, i);
+    focal_add(c.x, GtVec<GT>::cls(g.x), w.x, alpha, gamma, a);
+    focal_add(c.y, GtVec<GT>::cls(g.y), w.y, alpha, gamma, a);
+    focal_add(c.z, GtVec<GT>::cls(g.z), w.z, alpha, gamma, a);
+    focal_add(c.w, GtVec<GT>::cls(g.w), w.w, alpha, gamma, a);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // ragged tail
-    const size_t i = (n4 << 2) + threadIdx.x;
-    focal_add(conf[i], gt[i], weight ? weight[i] : 1.f, alpha, gamma, a);
-  }
+  // ragged tail (or everything when the vector path does not apply): grid-stride scalar loop
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    focal_add(conf[i], GtVec<GT>::cls(gt[i]), focal_w1(fw, i), alpha, gamma, a);
   double v[4] = {a.pos, a.neg, a.npos, a.nneg};
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -102,29 +150,26 @@ __device__ __forceinline__ float focal_grad(float conf, int gt, float w, float a
   return 0.f;
 }
 
-__global__ __launch_bounds__(kLossThreads) void focal_bwd_kernel(const float* __restrict__ conf, const short* __restrict__ gt,
-                                                                 const float* __restrict__ weight, size_t n, float alpha,
-                                                                 float gamma, const float* __restrict__ scales,
-                                                                 float* __restrict__ grad) {
+template <typename GT>
+__global__ __launch_bounds__(kLossThreads) void focal_bwd_kernel(const float* __restrict__ conf, const GT* __restrict__ gt, const FocalW fw,
+                                                                 size_t n, int vec_ok, float alpha, float gamma,
+                                                                 const float* __restrict__ scales, float* __restrict__ grad) {
   const float s_pos = scales[0], s_neg = scales[1];
-  const size_t n4 = n >> 2;
+  const size_t n4 = vec_ok ? (n >> 2) : 0;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     const float4 c = reinterpret_cast<const float4*>(conf)[i];
-    const short4 g = reinterpret_cast<const short4*>(gt)[i];
-    float4 w = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (weight) w = reinterpret_cast<const float4*>(weight)[i];
+    const typename GtVec<GT>::v4 g = reinterpret_cast<const typename GtVec<GT>::v4*>(gt)[i];
+    const float4 w = focal_w4(fw, i);
     float4 o;
-    o.x = focal_grad(c.x, g.x, w.x, alpha, gamma, s_pos, s_neg);
-    o.y = focal_grad(c.y, g.y, w.y, alpha, gamma, s_pos, s_neg);
-    o.z = focal_grad(c.z, g.z, w.z, alpha, gamma, s_pos, s_neg);
-    o.w = focal_grad(c.w, g.w, w.w, alpha, gamma, s_pos, s_neg);
+    o.x = focal_grad(c.x, GtVec<GT>::cls(g.x), w.x, alpha, gamma, s_pos, s_neg);
+    o.y = focal_grad(c.y, GtVec<GT>::cls(g.y), w.y, alpha, gamma, s_pos, s_neg);
+    o.z = focal_grad(c.z, GtVec<GT>::cls(g.z), w.z, alpha, gamma, s_pos, s_neg);
+    o.w = focal_grad(c.w, GtVec<GT>::cls(g.w), w.w, alpha, gamma, s_pos, s_neg);
     reinterpret_cast<float4*>(grad)[i] = o;
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const size_t i = (n4 << 2) + threadIdx.x;
-    grad[i] = focal_grad(conf[i], gt[i], weight ? weight[i] : 1.f, alpha, gamma, s_pos, s_neg);
-  }
+  for (size_t i = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    grad[i] = focal_grad(conf[i], GtVec<GT>::cls(gt[i]), focal_w1(fw, i), alpha, gamma, s_pos, s_neg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -233,33 +278,79 @@ bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; 
 
 size_t opp_focal_loss_ws_bytes(size_t n) { return (size_t)loss_blocks(n) * 4 * sizeof(double); }
 
-int opp_focal_loss_fwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma,
-                       double* sums, void* ws, size_t ws_bytes, hipStream_t stream) {
-  OPP_CHECK_ARG(conf && gt && sums && ws && n > 0, "focal_loss: null argument / empty input");
-  OPP_CHECK_ARG(aligned16(conf) && (reinterpret_cast<size_t>(gt) & 7) == 0 && (!weight || aligned16(weight)),
-                "focal_loss: conf / weight must be 16-byte aligned, conf_gt 8-byte aligned");
+namespace {
+// gt_kind: 0 int16, 1 fp32, 2 uint8 / bool.  The 16-byte vector path needs aligned operands and, with the outer-product
+// weight, rows of a multiple of four entries.
+int focal_check(const float* conf, const void* gt, int gt_kind, const float* weight, const float* mask0, const float* mask1, int N, int L, size_t n,
+                FocalW& fw, int& vec_ok) {
+  OPP_CHECK_ARG(conf && gt && n > 0, "focal_loss: null argument / empty input");
+  OPP_CHECK_ARG(gt_kind >= 0 && gt_kind <= 2, "focal_loss: conf_gt kind must be 0 (int16), 1 (fp32) or 2 (uint8)");
+  OPP_CHECK_ARG(!(weight && (mask0 || mask1)) && ((mask0 == nullptr) == (mask1 == nullptr)), "focal_loss: pass a weight array OR both mask vectors");
+  OPP_CHECK_ARG(!mask0 || (N > 0 && L > 0 && n % ((size_t)N * L) == 0), "focal_loss: mask vectors need n = B * N * L");
+  fw.w = weight;
+  fw.m0 = mask0;
+  fw.m1 = mask1;
+  fw.N = N;
+  fw.L = L;
+  const size_t gt_align = gt_kind == 0 ? 8 : (gt_kind == 1 ? 16 : 4);
+  vec_ok = aligned16(conf) && (reinterpret_cast<size_t>(gt) % gt_align) == 0 && (!weight || aligned16(weight)) &&
+           (!mask0 || (L % 4 == 0 && aligned16(mask1)));
+  return OPP_OK;
+}
+}  // namespace
+
+int opp_focal_loss_fwd_ex(const float* conf, const void* gt, int gt_kind, const float* weight, const float* mask0, const float* mask1, int N, int L,
+                          size_t n, float alpha, float gamma, double* sums, void* ws, size_t ws_bytes, hipStream_t stream) {
+  FocalW fw;
+  int vec_ok;
+  OPP_TRY(focal_check(conf, gt, gt_kind, weight, mask0, mask1, N, L, n, fw, vec_ok));
+  OPP_CHECK_ARG(sums && ws, "focal_loss: null output");
   const int blocks = loss_blocks(n);
   OPP_CHECK_ARG(ws_bytes >= (size_t)blocks * 4 * sizeof(double), "focal_loss: workspace too small");
   double* part = static_cast<double*>(ws);
   {
-    OppProfScope prof(OPP_PROF_FOCAL_FWD, stream, (double)n * (weight ? 10.0 : 6.0));
-    hipLaunchKernelGGL(focal_fwd_kernel, dim3(blocks), dim3(kLossThreads), 0, stream, conf, gt, weight, n, alpha, gamma, part);
+    const double gt_b = gt_kind == 0 ? 2.0 : (gt_kind == 1 ? 4.0 : 1.0);
+    OppProfScope prof(OPP_PROF_FOCAL_FWD, stream, (double)n * (4.0 + gt_b + (weight ? 4.0 : 0.0)));
+    if (gt_kind == 0)
+      hipLaunchKernelGGL(focal_fwd_kernel<short>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const short*>(gt), fw, n, vec_ok, alpha, gamma, part);
+    else if (gt_kind == 1)
+      hipLaunchKernelGGL(focal_fwd_kernel<float>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const float*>(gt), fw, n, vec_ok, alpha, gamma, part);
+    else
+      hipLaunchKernelGGL(focal_fwd_kernel<unsigned char>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const unsigned char*>(gt), fw, n, vec_ok, alpha, gamma, part);
   }
   hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(64), 0, stream, part, blocks, sums);
   OPP_CHECK_LAUNCH("focal_loss forward");
   return OPP_OK;
 }
 
-int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma,
-                       const float* scales, float* grad, hipStream_t stream) {
-  OPP_CHECK_ARG(conf && gt && scales && grad && n > 0, "focal_loss backward: null argument / empty input");
-  OPP_CHECK_ARG(aligned16(conf) && aligned16(grad) && (reinterpret_cast<size_t>(gt) & 7) == 0 && (!weight || aligned16(weight)),
-                "focal_loss backward: conf / grad / weight must be 16-byte aligned, conf_gt 8-byte aligned");
-  OppProfScope prof(OPP_PROF_FOCAL_BWD, stream, (double)n * (weight ? 14.0 : 10.0));
-  hipLaunchKernelGGL(focal_bwd_kernel, dim3(loss_blocks(n)), dim3(kLossThreads), 0, stream, conf, gt, weight, n, alpha, gamma, scales,
-                     grad);
+int opp_focal_loss_bwd_ex(const float* conf, const void* gt, int gt_kind, const float* weight, const float* mask0, const float* mask1, int N, int L,
+                          size_t n, float alpha, float gamma, const float* scales, float* grad, hipStream_t stream) {
+  FocalW fw;
+  int vec_ok;
+  OPP_TRY(focal_check(conf, gt, gt_kind, weight, mask0, mask1, N, L, n, fw, vec_ok));
+  OPP_CHECK_ARG(scales && grad, "focal_loss backward: null argument");
+  vec_ok = vec_ok && aligned16(grad);
+  const double gt_b = gt_kind == 0 ? 2.0 : (gt_kind == 1 ? 4.0 : 1.0);
+  OppProfScope prof(OPP_PROF_FOCAL_BWD, stream, (double)n * (8.0 + gt_b + (weight ? 4.0 : 0.0)));
+  const int blocks = loss_blocks(n);
+  if (gt_kind == 0)
+    hipLaunchKernelGGL(focal_bwd_kernel<short>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const short*>(gt), fw, n, vec_ok, alpha, gamma, scales, grad);
+  else if (gt_kind == 1)
+    hipLaunchKernelGGL(focal_bwd_kernel<float>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const float*>(gt), fw, n, vec_ok, alpha, gamma, scales, grad);
+  else
+    hipLaunchKernelGGL(focal_bwd_kernel<unsigned char>, dim3(blocks), dim3(kLossThreads), 0, stream, conf, static_cast<const unsigned char*>(gt), fw, n, vec_ok, alpha, gamma, scales, grad);
   OPP_CHECK_LAUNCH("focal_loss backward");
   return OPP_OK;
+}
+
+int opp_focal_loss_fwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma, double* sums, void* ws,
+                       size_t ws_bytes, hipStream_t stream) {
+  return opp_focal_loss_fwd_ex(conf, gt, 0, weight, nullptr, nullptr, 0, 0, n, alpha, gamma, sums, ws, ws_bytes, stream);
+}
+
+int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma, const float* scales, float* grad,
+                       hipStream_t stream) {
+  return opp_focal_loss_bwd_ex(conf, gt, 0, weight, nullptr, nullptr, 0, 0, n, alpha, gamma, scales, grad, stream);
 }
 
 namespace {

@@ -50,6 +50,11 @@ int opp_focal_loss_fwd(const float* conf, const short* gt, const float* weight, 
                        void* ws, size_t ws_bytes, hipStream_t stream);
 int opp_focal_loss_bwd(const float* conf, const short* gt, const float* weight, size_t n, float alpha, float gamma,
                        const float* scales, float* grad, hipStream_t stream);
+// gt_kind 0 int16 / 1 fp32 / 2 uint8; weight: a full array OR the outer product mask0[b][i] * mask1[b][j] (N rows per sample, L columns)
+int opp_focal_loss_fwd_ex(const float* conf, const void* gt, int gt_kind, const float* weight, const float* mask0, const float* mask1, int N, int L,
+                          size_t n, float alpha, float gamma, double* sums, void* ws, size_t ws_bytes, hipStream_t stream);
+int opp_focal_loss_bwd_ex(const float* conf, const void* gt, int gt_kind, const float* weight, const float* mask0, const float* mask1, int N, int L,
+                          size_t n, float alpha, float gamma, const float* scales, float* grad, hipStream_t stream);
 size_t opp_dual_softmax_bwd_ws_bytes(int B, int N, int L);
 int opp_dual_softmax_bwd(const float* g, const float* sim, const float* lse_row, const float* lse_col, int B, int N, int L, float* ds,
                          void* ws, size_t ws_bytes, hipStream_t stream);

@@ -18,8 +18,23 @@ import torch.nn as nn
 from . import _lib
 
 
+_GT_KINDS = {torch.int16: 0, torch.float32: 1, torch.uint8: 2, torch.bool: 2}
+
+
+def _gt_operand(conf_gt, dev):
+    """conf_matrix_gt as the kernels read it: int16, fp32 and 8-bit (bool) tensors go through untouched; other dtypes are cast
+    to fp32 (values other than 0 / 1 stay what they are and are ignored, like the reference's `== 1` / `== 0` masks)."""
+    g = conf_gt.to(dev)
+    if g.dtype not in _GT_KINDS:
+        g = g.to(torch.float32)
+    g = g.contiguous()
+    return g, _GT_KINDS[g.dtype]
+
+
 class _FocalLoss(torch.autograd.Function):
-    """pos_weight * mean(pos terms) + neg_weight * mean(neg terms) of losses.py:25-53 as one differentiable scalar."""
+    """pos_weight * mean(pos terms) + neg_weight * mean(neg terms) of losses.py:25-53 as one differentiable scalar.
+    `weight` is either a full tensor broadcastable to conf or a pair (mask0 [B, N], mask1 [B, L]) whose outer product it is
+    (Loss.compute_c_weight): the pair is multiplied inside the kernels, nothing of size B x N x L is materialised."""
 
     @staticmethod
     def forward(ctx, conf, conf_gt, weight, alpha, gamma, pos_w, neg_w):
@@ -28,34 +43,43 @@ class _FocalLoss(torch.autograd.Function):
         lib = _lib.load()
         dev = conf.device
         c = conf.detach().to(torch.float32).contiguous()
-        g = conf_gt.to(device=dev, dtype=torch.int16).contiguous()
+        g, kind = _gt_operand(conf_gt, dev)
         if g.shape != c.shape:
             raise ValueError("conf_matrix %s and conf_matrix_gt %s differ in shape" % (tuple(c.shape), tuple(g.shape)))
-        w = None
-        if weight is not None:
+        w = m0 = m1 = None
+        N = L = 0
+        if isinstance(weight, (tuple, list)):
+            m0 = weight[0].to(device=dev, dtype=torch.float32).contiguous()
+            m1 = weight[1].to(device=dev, dtype=torch.float32).contiguous()
+            if c.dim() != 3 or tuple(m0.shape) != tuple(c.shape[:2]) or tuple(m1.shape) != (c.shape[0], c.shape[2]):
+                raise ValueError("mask pair %s / %s does not match conf_matrix %s" % (tuple(m0.shape), tuple(m1.shape), tuple(c.shape)))
+            N, L = int(c.shape[1]), int(c.shape[2])
+        elif weight is not None:
             w = weight.to(device=dev, dtype=torch.float32).expand_as(c).contiguous()
         n = c.numel()
         stream = torch.cuda.current_stream(dev).cuda_stream
         sums = torch.empty(4, dtype=torch.float64, device=dev)
         ws = torch.empty(lib.opp_focal_loss_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
         with torch.cuda.device(dev):
-            _lib.check(lib.opp_focal_loss_forward(c.data_ptr(), g.data_ptr(), w.data_ptr() if w is not None else None, n,
-                                                  float(alpha), float(gamma), sums.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                  stream), "opp_focal_loss_forward")
+            _lib.check(lib.opp_focal_loss_forward_ex(c.data_ptr(), g.data_ptr(), kind, ptr(w), ptr(m0), ptr(m1), N, L, n, float(alpha),
+                                                     float(gamma), sums.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                       "opp_focal_loss_forward_ex")
         pos_sum, neg_sum, n_pos, n_neg = sums.unbind()
         pos_mean = pos_sum / n_pos.clamp(min=1.0)
         neg_mean = neg_sum / n_neg.clamp(min=1.0)
         # losses.py:44-53: an empty positive (negative) set drops that term instead of producing the NaN of an empty mean
         both = pos_w * pos_mean + neg_w * neg_mean
         loss = torch.where(n_pos == 0, neg_w * neg_mean, torch.where(n_neg == 0, pos_w * pos_mean, both))
-        ctx.save_for_backward(c, g, w if w is not None else torch.empty(0, device=dev), n_pos, n_neg)
-        ctx.meta = (float(alpha), float(gamma), float(pos_w), float(neg_w), conf.dtype, w is not None)
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(c, g, w if w is not None else empty, m0 if m0 is not None else empty, m1 if m1 is not None else empty, n_pos, n_neg)
+        ctx.meta = (float(alpha), float(gamma), float(pos_w), float(neg_w), conf.dtype, kind, w is not None, m0 is not None, N, L)
         return loss.to(torch.float32)
 
     @staticmethod
     def backward(ctx, grad_out):
-        c, g, w, n_pos, n_neg = ctx.saved_tensors
-        alpha, gamma, pos_w, neg_w, dtype, has_w = ctx.meta
+        c, g, w, m0, m1, n_pos, n_neg = ctx.saved_tensors
+        alpha, gamma, pos_w, neg_w, dtype, kind, has_w, has_m, N, L = ctx.meta
         lib = _lib.load()
         dev = c.device
         go = grad_out.to(torch.float64)
@@ -63,9 +87,10 @@ class _FocalLoss(torch.autograd.Function):
         grad = torch.empty_like(c)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(lib.opp_focal_loss_backward(c.data_ptr(), g.data_ptr(), w.data_ptr() if has_w else None, c.numel(),
-                                                   alpha, gamma, scales.data_ptr(), grad.data_ptr(), stream),
-                       "opp_focal_loss_backward")
+            _lib.check(lib.opp_focal_loss_backward_ex(c.data_ptr(), g.data_ptr(), kind, w.data_ptr() if has_w else None,
+                                                      m0.data_ptr() if has_m else None, m1.data_ptr() if has_m else None, N, L, c.numel(),
+                                                      alpha, gamma, scales.data_ptr(), grad.data_ptr(), stream),
+                       "opp_focal_loss_backward_ex")
         return grad.to(dtype), None, None, None, None, None, None
 
 
@@ -83,6 +108,7 @@ class Loss(nn.Module):
         self.fine_type = config["fine_type"]
 
     def compute_coarse_loss(self, conf, conf_gt, weight=None):
+        """weight: None, a tensor broadcastable to conf (the reference's argument), or the pair (mask0 [B, N], mask1 [B, L])"""
         if self.config["coarse_type"] != "focal":          # losses.py:56-57
             raise NotImplementedError
         return _FocalLoss.apply(conf, conf_gt, weight, self.config["focal_alpha"], self.config["focal_gamma"],
@@ -111,13 +137,21 @@ class Loss(nn.Module):
 
     @torch.no_grad()
     def compute_c_weight(self, data):
-        if "mask0" not in data:                                                # losses.py:103-111
+        """losses.py:103-111 (same values: mask0 [B, N] x mask1 [B, L] -> [B, N, L]).  `forward` does not call it: it hands the
+        two factors to the focal kernels, which multiply them on the fly."""
+        if "mask0" not in data:
             return None
         return data["mask0"].flatten(-2)[..., None] * data["mask1"].flatten(-2)[:, None]
 
+    @torch.no_grad()
+    def _c_weight_factors(self, data):
+        if "mask0" not in data:
+            return None
+        return data["mask0"].flatten(-2).to(torch.float32), data["mask1"].flatten(-2).to(torch.float32)
+
     def forward(self, data):
         scalars = {}
-        loss_c = self.compute_coarse_loss(data["conf_matrix"], data["conf_matrix_gt"], weight=self.compute_c_weight(data))
+        loss_c = self.compute_coarse_loss(data["conf_matrix"], data["conf_matrix_gt"], weight=self._c_weight_factors(data))
         loss = loss_c * self.config["coarse_weight"]                           # :125-128
         scalars["loss_c"] = loss_c.clone().detach().cpu()
         if "expec_f" in data:                                                  # :131-138
