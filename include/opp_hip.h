@@ -245,6 +245,21 @@ size_t opp_linear_backward_workspace_bytes(int M, int N, int K, int prec);
 int opp_linear_backward(const float* grad_out, const float* X, const float* W, int M, int N, int K, float* grad_x, float* grad_w,
                         int accumulate_grad_w, int prec, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training step: LinearAttention.forward with its backward (loftr_module/linear_attention.py:29-61) -------------------
+ * Raw projections q [B][L][nhead][D], k, v [B][S][nhead][D] (fp32, contiguous; D = 32 or 16), optional masks q_mask [B][L],
+ * kv_mask [B][S] (0 / 1 floats): out = (phi(q) KV) / (phi(q) . Ksum + 1e-6) * S with KV = sum_s phi(k_s)^T v_s / S,
+ * phi = elu + 1.  forward also returns KV [B][nhead][D][D] and Ksum [B][nhead][D], which backward takes back together with
+ * grad_out [B][L][nhead][D] and produces grad_q, grad_k, grad_v.  Token reductions are chunk partials summed in chunk order
+ * (deterministic). */
+size_t opp_linear_attention_train_workspace_bytes(int B, int L, int S, int nhead, int D);
+int opp_linear_attention_train_forward(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, int B,
+                                       int L, int S, int nhead, int D, float* out, float* kv, float* ks, void* workspace,
+                                       size_t workspace_bytes, void* stream);
+int opp_linear_attention_train_backward(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask,
+                                        const float* kv, const float* ks, const float* grad_out, int B, int L, int S, int nhead, int D,
+                                        float* grad_q, float* grad_k, float* grad_v, void* workspace, size_t workspace_bytes,
+                                        void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

@@ -94,6 +94,9 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_focal_loss_backward_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_size_t, c_float, c_float,
                                            c_void_p, c_void_p, c_void_p]),
+    "opp_linear_attention_train_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "opp_linear_attention_train_forward": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "opp_linear_attention_train_backward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "opp_linear_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "opp_linear_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

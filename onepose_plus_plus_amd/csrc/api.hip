@@ -1415,6 +1415,21 @@ extern "C" int opp_linear_backward(const float* grad_out, const float* X, const 
   return opp_linear_bwd(grad_out, X, W, M, N, K, grad_x, grad_w, accumulate_grad_w, prec, ws, ws_bytes, (hipStream_t)stream);
 }
 
+extern "C" size_t opp_linear_attention_train_workspace_bytes(int B, int L, int S, int nhead, int D) { return opp_linattn_train_ws_bytes(B, L, S, nhead, D); }
+
+extern "C" int opp_linear_attention_train_forward(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, int B,
+                                                  int L, int S, int nhead, int D, float* out, float* kv, float* ks, void* ws, size_t ws_bytes,
+                                                  void* stream) {
+  return opp_linattn_train_fwd(q, k, v, q_mask, kv_mask, B, L, S, nhead, D, 1e-6f, out, kv, ks, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int opp_linear_attention_train_backward(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask,
+                                                   const float* kv, const float* ks, const float* grad_out, int B, int L, int S, int nhead, int D,
+                                                   float* grad_q, float* grad_k, float* grad_v, void* ws, size_t ws_bytes, void* stream) {
+  return opp_linattn_train_bwd(q, k, v, q_mask, kv_mask, kv, ks, grad_out, B, L, S, nhead, D, 1e-6f, grad_q, grad_k, grad_v, ws, ws_bytes,
+                               (hipStream_t)stream);
+}
+
 extern "C" int opp_conv_packed_k(int cin, int ks) { return opp_conv_k(cin, ks); }
 
 extern "C" int opp_pack_h2(const float* in, float* out, size_t n, float* scale2, void* stream) {

@@ -1,0 +1,283 @@
+// LinearAttention.forward (loftr_module/linear_attention.py:29-61) with its BACKWARD, for the training step
+// (PL_OnePosePlus.training_step, src/lightning_model/OnePosePlus_lightning_model.py:54-81): the node the
+// re-evaluated training graph uses instead of three torch.einsum calls and their autograd (bmm / einsum: 17 ms of a 120 ms
+// step at B = 4, 7000 points).
+//
+// Per sample b and head h (D = C / nhead = 32 coarse, 16 fine), raw projections q [B][L][H][D], k, v [B][S][H][D]:
+//   Qp = (elu(q) + 1) mq,  Kp = (elu(k) + 1) mk,  Vs = v mk / S
+//   KV = sum_s Kp[s]^T Vs[s]  [D][D],  ks = sum_s Kp[s]  [D]
+//   den[l] = Qp[l] . ks + eps,  num[l] = Qp[l] KV,  out[l] = num[l] / den[l] * S
+// Backward, g = d loss / d out:
+//   gnum = g S / den,  gden = -(g . num) S / den^2
+//   gQp[l] = gnum[l] KV^T + gden[l] ks          gKV = sum_l Qp[l]^T gnum[l]       gks = sum_l gden[l] Qp[l]
+//   gKp[s] = Vs[s] gKV^T + gks                  gVs[s] = Kp[s] gKV
+//   gq = gQp phi'(q) mq,  gk = gKp phi'(k) mk,  gv = gVs mk / S            (phi'(x) = 1 for x > 0, exp(x) otherwise)
+// All reductions over tokens are chunk partials summed in chunk order (deterministic).  fp32 fmaf arithmetic.
+// Kernels are bandwidth-bound (every activation read once or twice per pass); a block = 64 tokens of one (sample, head).
+#include "opp_internal.h"
+
+namespace {
+
+constexpr int kTok = 64;        // tokens per block
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+__device__ __forceinline__ float dphi(float x) { return x > 0.f ? 1.f : __expf(x); }
+
+// partial KV / ks of one chunk of source tokens: a[t][d] (x) b[t][v] summed over t.  MODE 0: a = Kp, b = Vs (forward);
+// MODE 1: a = Qp, b = gnum, and the vector partial is sum_t gden[t] Qp[t] (backward; needs KV, ks of the forward)
+template <int D, int MODE>
+__global__ __launch_bounds__(kThreads) void la_outer_kernel(const float* __restrict__ x,      // MODE 0: k ; MODE 1: q     [B][T][H][D]
+                                                            const float* __restrict__ y,      // MODE 0: v ; MODE 1: g
+                                                            const float* __restrict__ mask,   // [B][T] or null
+                                                            const float* __restrict__ kv, const float* __restrict__ ks,   // MODE 1 only
+                                                            int T, int H, float inv_s, float s_len, float eps,
+                                                            float* __restrict__ part_m, float* __restrict__ part_v) {
+  __shared__ float a_sh[kTok][D + 1], b_sh[kTok][D + 1], w_sh[kTok];
+  __shared__ float kv_sh[MODE == 1 ? D * D : 1], ks_sh[MODE == 1 ? D : 1];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int nchunks = gridDim.x;
+  const int t0 = chunk * kTok, nt = min(kTok, T - t0);
+  const int tid = threadIdx.x;
+  const size_t row = (size_t)H * D;
+  if (MODE == 1) {
+    for (int i = tid; i < D * D; i += kThreads) kv_sh[i] = kv[((size_t)b * H + h) * D * D + i];
+    if (tid < D) ks_sh[tid] = ks[((size_t)b * H + h) * D + tid];
+  }
+  for (int i = tid; i < kTok * D; i += kThreads) {
+    const int t = i / D, d = i - t * D;
+    float av = 0.f, bv = 0.f;
+    if (t < nt) {
+      const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + d;
+      const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+      av = phi(x[o]) * m;
+      bv = MODE == 0 ? y[o] * m * inv_s : y[o];
+    }
+    a_sh[t][d] = av;
+    b_sh[t][d] = bv;
+  }
+  __syncthreads();
+  if (MODE == 1) {
+    // per token: den, num . g  ->  gnum = g S / den (overwrites b_sh), gden
+    for (int t = tid; t < kTok; t += kThreads) {
+      float den = eps, dot = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < D; ++d) den = fmaf(a_sh[t][d], ks_sh[d], den);
+      for (int v = 0; v < D; ++v) {
+        float num = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) num = fmaf(a_sh[t][d], kv_sh[d * D + v], num);
+        dot = fmaf(b_sh[t][v], num, dot);
+      }
+      const float z = 1.0f / den;
+      w_sh[t] = -(dot * s_len) * z * z;
+      const float sc = s_len * z;
+      for (int v = 0; v < D; ++v) b_sh[t][v] *= sc;
+    }
+    __syncthreads();
+  }
+  // outer-product sums: thread owns entries (d, v) with d * D + v = tid, tid + 256, ...
+  float* pm = part_m + (((size_t)b * H + h) * nchunks + chunk) * (D * D);
+  for (int e = tid; e < D * D; e += kThreads) {
+    const int d = e / D, v = e - d * D;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < kTok; ++t) acc = fmaf(a_sh[t][d], b_sh[t][v], acc);
+    pm[e] = acc;
+  }
+  if (tid < D) {
+    float acc = 0.f;
+    for (int t = 0; t < kTok; ++t) acc = MODE == 0 ? acc + a_sh[t][tid] : fmaf(w_sh[t], a_sh[t][tid], acc);
+    part_v[(((size_t)b * H + h) * nchunks + chunk) * D + tid] = acc;
+  }
+}
+
+// out[bh][e] = sum over chunks in chunk order
+__global__ void la_chunk_reduce_kernel(const float* __restrict__ part, int nchunks, int per, size_t n_bh, float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_bh * per) return;
+  const size_t bh = i / per;
+  const int e = (int)(i - bh * per);
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += part[(bh * nchunks + c) * per + e];
+  out[i] = s;
+}
+
+// per query token: MODE 0 forward out = num / den * S ; MODE 1 backward gq = (gnum KV^T + gden ks) phi'(q) mq
+template <int D, int MODE>
+__global__ __launch_bounds__(kThreads) void la_query_kernel(const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ mask,
+                                                            const float* __restrict__ kv, const float* __restrict__ ks, int T, int H,
+                                                            float s_len, float eps, float* __restrict__ out) {
+  __shared__ float q_sh[kTok][D + 1], g_sh[kTok][D + 1], kv_sh[D * D], ks_sh[D], z_sh[kTok], gd_sh[kTok];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t0 = chunk * kTok, nt = min(kTok, T - t0);
+  const int tid = threadIdx.x;
+  const size_t row = (size_t)H * D;
+  for (int i = tid; i < D * D; i += kThreads) kv_sh[i] = kv[((size_t)b * H + h) * D * D + i];
+  if (tid < D) ks_sh[tid] = ks[((size_t)b * H + h) * D + tid];
+  for (int i = tid; i < kTok * D; i += kThreads) {
+    const int t = i / D, d = i - t * D;
+    float qv = 0.f, gv = 0.f;
+    if (t < nt) {
+      const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + d;
+      const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+      qv = phi(q[o]) * m;
+      if (MODE == 1) gv = g[o];
+    }
+    q_sh[t][d] = qv;
+    g_sh[t][d] = gv;
+  }
+  __syncthreads();
+  for (int t = tid; t < kTok; t += kThreads) {
+    float den = eps;
+#pragma unroll 4
+    for (int d = 0; d < D; ++d) den = fmaf(q_sh[t][d], ks_sh[d], den);
+    const float z = 1.0f / den;
+    z_sh[t] = z;
+    if (MODE == 1) {
+      float dot = 0.f;
+      for (int v = 0; v < D; ++v) {
+        float num = 0.f;
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) num = fmaf(q_sh[t][d], kv_sh[d * D + v], num);
+        dot = fmaf(g_sh[t][v], num, dot);
+      }
+      gd_sh[t] = -(dot * s_len) * z * z;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kTok * D; i += kThreads) {
+    const int t = i / D, e = i - t * D;
+    if (t >= nt) continue;
+    const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + e;
+    if (MODE == 0) {
+      float num = 0.f;
+#pragma unroll 4
+      for (int d = 0; d < D; ++d) num = fmaf(q_sh[t][d], kv_sh[d * D + e], num);
+      out[o] = (num * z_sh[t]) * s_len;
+    } else {
+      // gQp[e] = sum_v gnum[v] KV[e][v] + gden ks[e]
+      const float sc = s_len * z_sh[t];
+      float acc = gd_sh[t] * ks_sh[e];
+#pragma unroll 4
+      for (int v = 0; v < D; ++v) acc = fmaf(g_sh[t][v] * sc, kv_sh[e * D + v], acc);
+      const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+      out[o] = acc * dphi(q[o]) * m;
+    }
+  }
+}
+
+// per source token (backward): gk = (Vs gKV^T + gks) phi'(k) mk ; gv = (Kp gKV) mk / S
+template <int D>
+__global__ __launch_bounds__(kThreads) void la_source_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask,
+                                                                 const float* __restrict__ gkv, const float* __restrict__ gks, int T, int H, float inv_s,
+                                                                 float* __restrict__ gk, float* __restrict__ gv) {
+  __shared__ float k_sh[kTok][D + 1], v_sh[kTok][D + 1], kv_sh[D * D], ks_sh[D];
+  const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int t0 = chunk * kTok, nt = min(kTok, T - t0);
+  const int tid = threadIdx.x;
+  const size_t row = (size_t)H * D;
+  for (int i = tid; i < D * D; i += kThreads) kv_sh[i] = gkv[((size_t)b * H + h) * D * D + i];
+  if (tid < D) ks_sh[tid] = gks[((size_t)b * H + h) * D + tid];
+  for (int i = tid; i < kTok * D; i += kThreads) {
+    const int t = i / D, d = i - t * D;
+    float kv_ = 0.f, vv = 0.f;
+    if (t < nt) {
+      const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + d;
+      const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+      kv_ = phi(k[o]) * m;
+      vv = v[o] * m * inv_s;
+    }
+    k_sh[t][d] = kv_;
+    v_sh[t][d] = vv;
+  }
+  __syncthreads();
+  for (int i = tid; i < kTok * D; i += kThreads) {
+    const int t = i / D, e = i - t * D;
+    if (t >= nt) continue;
+    const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + e;
+    const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+    float a = ks_sh[e], c = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < D; ++j) {
+      a = fmaf(v_sh[t][j], kv_sh[e * D + j], a);     // gKp[e] = sum_v Vs[v] gKV[e][v] + gks[e]
+      c = fmaf(k_sh[t][j], kv_sh[j * D + e], c);     // gVs[e] = sum_d Kp[d] gKV[d][e]
+    }
+    gk[o] = a * dphi(k[o]) * m;
+    gv[o] = c * m * inv_s;
+  }
+}
+
+struct Plan {
+  int cq, cs;
+  size_t off_pm, off_pv, total;    // floats
+};
+Plan make_plan(int B, int L, int S, int H, int D) {
+  Plan p;
+  p.cq = opp_cdiv(L, kTok);
+  p.cs = opp_cdiv(S, kTok);
+  const int cm = p.cq > p.cs ? p.cq : p.cs;
+  p.off_pm = 0;
+  p.off_pv = (size_t)B * H * cm * D * D;
+  p.total = p.off_pv + (size_t)B * H * cm * D + 64;
+  return p;
+}
+
+template <int D>
+int fwd_impl(const float* q, const float* k, const float* v, const float* qm, const float* km, int B, int L, int S, int H, float eps, float* out,
+             float* kv, float* ks, float* ws, hipStream_t st) {
+  const Plan p = make_plan(B, L, S, H, D);
+  const float inv_s = 1.0f / (float)S, s_len = (float)S;
+  hipLaunchKernelGGL((la_outer_kernel<D, 0>), dim3(p.cs, H, B), dim3(kThreads), 0, st, k, v, km, (const float*)nullptr, (const float*)nullptr, S, H,
+                     inv_s, s_len, eps, ws + p.off_pm, ws + p.off_pv);
+  const size_t nbh = (size_t)B * H;
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cs, D * D, nbh, kv);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cs, D, nbh, ks);
+  hipLaunchKernelGGL((la_query_kernel<D, 0>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, (const float*)nullptr, qm, kv, ks, L, H, s_len, eps, out);
+  OPP_CHECK_LAUNCH("linattn_train forward");
+  return OPP_OK;
+}
+
+template <int D>
+int bwd_impl(const float* q, const float* k, const float* v, const float* qm, const float* km, const float* kv, const float* ks, const float* g, int B,
+             int L, int S, int H, float eps, float* gq, float* gk, float* gv, float* ws, hipStream_t st) {
+  const Plan p = make_plan(B, L, S, H, D);
+  const float inv_s = 1.0f / (float)S, s_len = (float)S;
+  const size_t nbh = (size_t)B * H;
+  float* gkv = ws + p.total;                    // [B][H][D][D] + [B][H][D] behind the partials
+  float* gks = gkv + nbh * D * D;
+  hipLaunchKernelGGL((la_outer_kernel<D, 1>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, g, qm, kv, ks, L, H, inv_s, s_len, eps, ws + p.off_pm,
+                     ws + p.off_pv);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cq, D * D, nbh, gkv);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cq, D, nbh, gks);
+  hipLaunchKernelGGL((la_query_kernel<D, 1>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, g, qm, kv, ks, L, H, s_len, eps, gq);
+  hipLaunchKernelGGL((la_source_bwd_kernel<D>), dim3(p.cs, H, B), dim3(kThreads), 0, st, k, v, km, gkv, gks, S, H, inv_s, gk, gv);
+  OPP_CHECK_LAUNCH("linattn_train backward");
+  return OPP_OK;
+}
+
+}  // namespace
+
+size_t opp_linattn_train_ws_bytes(int B, int L, int S, int H, int D) {
+  if (B <= 0 || L <= 0 || S <= 0 || H <= 0 || D <= 0) return 256;
+  return (make_plan(B, L, S, H, D).total + (size_t)B * H * (D * D + D) + 64) * sizeof(float);
+}
+
+int opp_linattn_train_fwd(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, int B, int L, int S, int H, int D,
+                          float eps, float* out, float* kv, float* ks, void* ws, size_t ws_bytes, hipStream_t stream) {
+  OPP_CHECK_ARG(q && k && v && out && kv && ks && ws && B > 0 && L > 0 && S > 0 && H > 0, "linattn_train: null / empty argument");
+  OPP_CHECK_ARG(D == 32 || D == 16, "linattn_train: head width must be 32 or 16 (got %d)", D);
+  OPP_CHECK_ARG(ws_bytes >= opp_linattn_train_ws_bytes(B, L, S, H, D), "linattn_train: workspace too small");
+  return D == 32 ? fwd_impl<32>(q, k, v, q_mask, kv_mask, B, L, S, H, eps, out, kv, ks, static_cast<float*>(ws), stream)
+                 : fwd_impl<16>(q, k, v, q_mask, kv_mask, B, L, S, H, eps, out, kv, ks, static_cast<float*>(ws), stream);
+}
+
+int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, const float* kv, const float* ks,
+                          const float* grad_out, int B, int L, int S, int H, int D, float eps, float* gq, float* gk, float* gv, void* ws,
+                          size_t ws_bytes, hipStream_t stream) {
+  OPP_CHECK_ARG(q && k && v && kv && ks && grad_out && gq && gk && gv && ws && B > 0 && L > 0 && S > 0 && H > 0, "linattn_train backward: null / empty argument");
+  OPP_CHECK_ARG(D == 32 || D == 16, "linattn_train backward: head width must be 32 or 16 (got %d)", D);
+  OPP_CHECK_ARG(ws_bytes >= opp_linattn_train_ws_bytes(B, L, S, H, D), "linattn_train backward: workspace too small");
+  return D == 32 ? bwd_impl<32>(q, k, v, q_mask, kv_mask, kv, ks, grad_out, B, L, S, H, eps, gq, gk, gv, static_cast<float*>(ws), stream)
+                 : bwd_impl<16>(q, k, v, q_mask, kv_mask, kv, ks, grad_out, B, L, S, H, eps, gq, gk, gv, static_cast<float*>(ws), stream);
+}

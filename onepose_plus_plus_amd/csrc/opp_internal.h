@@ -140,6 +140,13 @@ int opp_gemm_ss(const OppGemmSS& g, hipStream_t stream);
 size_t opp_linear_bwd_ws_bytes(int M, int N, int K, int prec);
 int opp_linear_bwd(const float* dY, const float* X, const float* W, int M, int N, int K, float* dX, float* dW, int accumulate_dw, int prec,
                    void* ws, size_t ws_bytes, hipStream_t stream);
+// linattn_train.hip -- LinearAttention forward + backward of the training step (raw q, k, v [B][T][H][D], D = 32 / 16)
+size_t opp_linattn_train_ws_bytes(int B, int L, int S, int H, int D);
+int opp_linattn_train_fwd(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, int B, int L, int S, int H, int D,
+                          float eps, float* out, float* kv, float* ks, void* ws, size_t ws_bytes, hipStream_t stream);
+int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, const float* kv, const float* ks,
+                          const float* grad_out, int B, int L, int S, int H, int D, float eps, float* gq, float* gk, float* gv, void* ws,
+                          size_t ws_bytes, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);

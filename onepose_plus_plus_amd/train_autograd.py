@@ -76,6 +76,56 @@ class HipLinear(torch.autograd.Function):
         return (dx.view(*lead, K) if need_x else None), dw, None
 
 
+class HipLinearAttention(torch.autograd.Function):
+    """LinearAttention.forward (loftr_module/linear_attention.py:29-61) with forward and backward in libopp_hip.so
+    (csrc/linattn_train.hip): q [B, L, H, D], k, v [B, S, H, D] raw projections, optional 0 / 1 masks [B, L], [B, S]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, q_mask, kv_mask):
+        from . import _lib
+        lib = _lib.load()
+        dev = q.device
+        qc, kc, vc = (t.to(torch.float32).contiguous() for t in (q, k, v))
+        B, L, H, D = qc.shape
+        S = kc.shape[1]
+        qm = q_mask.to(device=dev, dtype=torch.float32).contiguous() if q_mask is not None else None
+        km = kv_mask.to(device=dev, dtype=torch.float32).contiguous() if kv_mask is not None else None
+        out = torch.empty_like(qc)
+        kv = torch.empty((B, H, D, D), dtype=torch.float32, device=dev)
+        ks = torch.empty((B, H, D), dtype=torch.float32, device=dev)
+        nb = lib.opp_linear_attention_train_workspace_bytes(B, L, S, H, D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_linear_attention_train_forward(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), ptr(qm), ptr(km), B, L, S, H, D,
+                                                              out.data_ptr(), kv.data_ptr(), ks.data_ptr(), ws.data_ptr(), nb,
+                                                              torch.cuda.current_stream(dev).cuda_stream), "opp_linear_attention_train_forward")
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(qc, kc, vc, kv, ks, qm if qm is not None else empty, km if km is not None else empty)
+        ctx.meta = (qm is not None, km is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        qc, kc, vc, kv, ks, qm, km = ctx.saved_tensors
+        has_qm, has_km = ctx.meta
+        dev = qc.device
+        B, L, H, D = qc.shape
+        S = kc.shape[1]
+        gc = g.to(torch.float32).contiguous()
+        gq, gk, gv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        nb = lib.opp_linear_attention_train_workspace_bytes(B, L, S, H, D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_linear_attention_train_backward(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), qm.data_ptr() if has_qm else None,
+                                                               km.data_ptr() if has_km else None, kv.data_ptr(), ks.data_ptr(), gc.data_ptr(),
+                                                               B, L, S, H, D, gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), ws.data_ptr(), nb,
+                                                               torch.cuda.current_stream(dev).cuda_stream), "opp_linear_attention_train_backward")
+        return gq, gk, gv, None, None
+
+
 def _linear(x, w):
     """F.linear(x, w) of a transformer Linear; on the device with the HIP backward unless switched off"""
     if _HIP_LINEAR_PREC is not None and x.is_cuda and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0:
@@ -133,6 +183,8 @@ def _kpt_encoding(p, kpts, desc):
 
 
 def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loftr_module/linear_attention.py:29-61
+    if _HIP_LINEAR_PREC is not None and q.is_cuda and q.shape[-1] in (16, 32) and eps == 1e-6:
+        return HipLinearAttention.apply(q, k, v, q_mask, kv_mask)
     Q, K = F.elu(q) + 1, F.elu(k) + 1
     if q_mask is not None:
         Q = Q * q_mask[:, :, None, None]

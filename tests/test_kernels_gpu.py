@@ -447,3 +447,34 @@ def test_linear_backward_vs_fp64(M, K, N, prec):
     HipLinear.apply(x2, w2, prec).backward(gy)
     torch.cuda.synchronize()
     assert torch.equal(x2.grad, x.grad) and torch.equal(w2.grad, w.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,S,H,D,masked", [(2, 96, 77, 8, 32, False), (1, 4096, 5000, 8, 32, True), (3, 25, 1, 8, 16, False),
+                                               (4, 1, 25, 8, 16, False), (2, 130, 64, 8, 32, True)])
+def test_linear_attention_backward_vs_fp64(B, L, S, H, D, masked):
+    """LinearAttention.forward with its backward in libopp_hip.so (csrc/linattn_train.hip; the node the training step's graph uses
+    instead of three einsums, loftr_module/linear_attention.py:29-61) against torch autograd on an fp64 evaluation of the
+    reference formula: output and the three input gradients, with and without masks, coarse (D = 32) and fine (D = 16) heads;
+    two runs are bit-identical (chunk partials summed in order)."""
+    from onepose_plus_plus_amd.train_autograd import HipLinearAttention, _linear_attention
+    g = torch.Generator().manual_seed(B * 1000 + L + S)
+    q = torch.randn(B, L, H, D, generator=g).cuda().requires_grad_(True)
+    k = torch.randn(B, S, H, D, generator=g).cuda().requires_grad_(True)
+    v = torch.randn(B, S, H, D, generator=g).cuda().requires_grad_(True)
+    go = torch.randn(B, L, H, D, generator=g).cuda()
+    qm = (torch.rand(B, L, generator=g) < 0.8).float().cuda() if masked else None
+    km = (torch.rand(B, S, generator=g) < 0.8).float().cuda() if masked else None
+    out = HipLinearAttention.apply(q, k, v, qm, km)
+    out.backward(go)
+    torch.cuda.synchronize()
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    ref = _linear_attention(qd, kd, vd, qm.double() if masked else None, km.double() if masked else None)     # fp64 tensors: the torch formula
+    ref.backward(go.double())
+    for got, want, what in ((out.detach(), ref.detach(), "out"), (q.grad, qd.grad, "gq"), (k.grad, kd.grad, "gk"), (v.grad, vd.grad, "gv")):
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1.0), (what, err, want.abs().max().item())     # O(1) inputs: fp32-level absolute floor
+    q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    HipLinearAttention.apply(q2, k2, v2, qm, km).backward(go)
+    torch.cuda.synchronize()
+    assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
