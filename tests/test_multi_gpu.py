@@ -103,3 +103,79 @@ def test_sharded_objects_over_rccl_match_single_process():
         out = ops.run_model(single, make_inputs(300, (128, 128), 10 + r))
         assert torch.equal(out["i_ids"].cpu(), res[r][0]) and torch.equal(out["j_ids"].cpu(), res[r][1])
         assert torch.equal(out["mconf"].cpu(), res[r][2])
+
+
+def _nccl_train_worker(rank, world, port, q, mode):
+    """One data-parallel training step (train()-mode HIP forward, fine_supervision, Loss, backward) per rank on a
+    rank-specific batch; `mode` = 'averager' (sharding.GradientAverager: one flat all-reduce) or 'ddp'."""
+    import torch.distributed as dist
+    from tests import helpers as H
+    from tests import hip_ops as ops
+    from tests.golden.cases import LOSS_CONFIG
+    from onepose_plus_plus_amd.losses import Loss, fine_supervision
+    from onepose_plus_plus_amd.sharding import GradientAverager
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        cfg, sd, data = H.train_setup("train_b4_64x96_n150")
+        model = ops.make_model(cfg, sd).to(dev).train()
+        g = torch.Generator().manual_seed(500 + rank)
+        data["query_image"] = (data["query_image"] + 0.05 * torch.randn(data["query_image"].shape, generator=g)).clamp(0, 1)
+        B, N = data["keypoints3d"].shape[:2]
+        data["fine_location_matrix_gt"] = torch.full((B, N, data["conf_matrix_gt"].shape[2], 2), -50.0)
+        d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in data.items()}
+        hparams = {"OnePosePlus": cfg, "loss": dict(LOSS_CONFIG)}
+        loss_mod = Loss(hparams["loss"]).train()
+        if mode == "ddp":
+            wrapped = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank], find_unused_parameters=False)
+            avg = None
+        else:
+            wrapped = model
+            avg = GradientAverager(model)
+        wrapped(d)
+        fine_supervision(d, hparams)
+        loss_mod(d)
+        d["loss"].backward()
+        params = [p for p in model.parameters() if p.requires_grad]
+        if avg is not None:
+            own = torch.cat([p.grad.flatten() for p in params]).clone()
+            avg.average()
+        flat = torch.cat([p.grad.flatten() for p in params])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(gathered[0], t) for t in gathered[1:])
+        mean_ok = True
+        if avg is not None:
+            owns = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(owns, own)
+            want = sum(owns) / world
+            mean_ok = bool(torch.allclose(flat, want, rtol=1e-6, atol=1e-9)) and not torch.equal(owns[0], owns[1])
+        q.put((rank, same, mean_ok, bool(torch.isfinite(flat).all()), float(flat.abs().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+@pytest.mark.parametrize("mode", ["averager", "ddp"])
+def test_data_parallel_training_step_over_rccl(mode):
+    """BASELINE configs[4] (Lightning DDP upstream): after the gradient exchange both ranks hold the same gradients (and,
+    for the flat averager, exactly the mean of the two ranks' own gradients)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() + (11 if mode == "ddp" else 13)) % 2000
+    procs = [ctx.Process(target=_nccl_train_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=900)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        same, mean_ok, finite, mass = res[r]
+        assert same and mean_ok and finite and mass > 0
