@@ -82,8 +82,9 @@ DEPTH_OF_CFG = {10: 3, 11: 4}
 IMAGES_PER_STEP = 16
 # MFMA-bound kernels outside opp_gemm_kernel: (profile symbol, kernel name, description); work = algorithmic FLOPs
 MFMA_SYMBOLS = [
-    (1009, "enc_chain_kernel", "one encoder layer behind the QKV projection in ONE launch: attention apply, merge, norm1, mlp.0, ReLU, "
-                               "mlp.2, norm2, residual on 32-token tiles held in LDS (2 x T x (7 C^2 + 32 C) FLOP)"),
+    (1009, "enc_layer64_kernel", "one encoder layer behind the QKV projection in ONE launch: attention apply, merge, norm1, mlp.0, ReLU, "
+                                 "mlp.2, norm2, residual on 64-token tiles held in LDS (enc_chain_kernel on 32-token tiles when "
+                                 "encoder_fusion = 1); 2 x T x (7 C^2 + 32 C) FLOP"),
     (1012, "gemm_ss_kernel<3>", "coarse score GEMM on operands pre-split once, LDS-DMA staged, + dual-softmax statistics + score matrix"),
     (1010, "gemm_ss_kernel<1>", "coarse score GEMM sweep 1 (statistics only; two-sweep matcher)"),
     (1011, "gemm_ss_kernel<2>", "coarse score GEMM sweep 2 (confidences written once; two-sweep matcher)"),
@@ -311,7 +312,19 @@ def run(args):
 
     roof = None
     if prof:
+        # a kernel's own duration: one forward in flight AND the FPN fine branch on the same stream (with opp_config.fpn_overlap
+        # the coarse-level kernels share the CUs with the fine-branch convolutions and every launch of both stretches)
+        overlap = [getattr(m, "fpn_overlap", True) for m in models]
+        for m in models:
+            m.set_fpn_overlap(False).to(dev)
+        step(0, 0)
+        torch.cuda.synchronize(dev)
         roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps * ips, 20))
+        for m, o in zip(models, overlap):
+            m.set_fpn_overlap(o).to(dev)
+        for k in range(n_streams):
+            step(0, k)
+        torch.cuda.synchronize(dev)
 
     legs = {}
     if rank == 0 and world == 1 and not args.no_legs:
@@ -368,6 +381,9 @@ def compact_legs(legs):
     t = legs.get("throughput_tiles_leg")
     if t:
         out["throughput_tiles_images_per_s"] = t.get("value")
+    t = legs.get("coarse_only_without_unused_fine_map_leg")
+    if t:
+        out["coarse_only_without_unused_fine_map_images_per_s"] = t.get("value")
     f = legs.get("fine_leg") or {}
     if "ms_per_forward" in f:
         out["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak")}
@@ -410,7 +426,8 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     several forwards in flight kernels of different streams share the CUs, so a kernel's own launch duration is only
     meaningful on its own: every symbol is timed in a single-stream pass of the same steps right after the timed
     region."""
-    how = "HIP events on the launch stream, single-stream pass of %d steps after the timed region" % nsteps
+    how = ("HIP events on the launch stream, single-stream pass of %d forwards after the timed region, fpn_overlap off "
+           "(every kernel alone on the chip)" % nsteps)
     pid = PREC_ID[precision]
     peak = MFMA_PEAK[precision]
     tpath = os.path.join(ROOT, "profiles", "traffic_symbols_%s.json" % precision)
@@ -500,6 +517,25 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
                                         "note": "opp_config.tile_policy = 1: bit-identical results, fewer / larger tiles per launch"}
         for m in models:
             m.set_tile_policy("latency").to(dev)
+    if not args.fine:
+        # the same coarse-only workload without the fine feature map nothing reads (model.set_skip_unused_fine_map: an opt-in
+        # dead-branch elimination the reference cannot do; NOT the headline, which launches every operator of the reference)
+        for m in models:
+            m.set_skip_unused_fine_map(True)
+        for k in range(n_streams):
+            step(0, k)
+        torch.cuda.synchronize(dev)
+        run_steps(2 * n_streams)
+        n = min(args.steps * max(1, args.images_per_step), 96)
+        t1 = time.perf_counter()
+        run_steps(n)
+        torch.cuda.synchronize(dev)
+        legs["coarse_only_without_unused_fine_map_leg"] = {
+            "value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
+            "note": "fine_matching.enable = False and the FPN fine branch (dead: not an output, read by nothing) not launched; "
+                    "match indices / confidences identical"}
+        for m in models:
+            m.set_skip_unused_fine_map(False)
     try:
         legs["fine_leg"] = fine_leg(torch, dev, precision, lib, _lib)
     except Exception as e:      # the fixture is optional for the headline

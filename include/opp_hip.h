@@ -181,8 +181,10 @@ int opp_coarse_match(opp_ctx* ctx, const float* feat3d, const float* feat2d, int
                      void* stream);
 
 /* Whole coarse level in one call: backbone -> tokens -> loftr_coarse -> coarse matching
- * (OnePosePlusModel.py:116-167).  feat_f is kept for the fine stage.  tokens3d_pre: optional
- * result of opp_encode_points for this object (NULL = encode kpts/bank_c here). */
+ * (OnePosePlusModel.py:116-167).  feat_f is kept for the fine stage; feat_f = NULL says the caller runs no fine
+ * stage (fine_matching.enable = False, OnePosePlusModel.py:169-176): the fine map is then dead -- not an output, read by
+ * nothing -- and the FPN branch that produces it is not launched (every output of this call is unchanged).
+ * tokens3d_pre: optional result of opp_encode_points for this object (NULL = encode kpts/bank_c here). */
 size_t opp_forward_coarse_workspace_bytes(const opp_ctx* ctx, int H, int W, int n_points);
 int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W, const float* pe,
                        const float* kpts, const float* bank_c, const float* tokens3d_pre, int n_points,

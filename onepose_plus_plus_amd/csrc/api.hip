@@ -1256,7 +1256,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
                                   long long* i_ids, long long* j_ids, float* mconf, float* mkpts_c, float* mkpts_3d,
                                   int* count, void* ws, size_t ws_bytes, void* stream) {
   FlagScope flag_scope(ctx);
-  OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && (bank_c || tokens3d_pre) && feat_f && conf && ws, "forward_coarse: null argument");
+  OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && (bank_c || tokens3d_pre) && conf && ws, "forward_coarse: null argument");
   OPP_CHECK_ARG(n > 0, "forward_coarse: empty point cloud");
   OPP_CHECK_ARG(!ctx->cfg.pos_enc_enable || pe, "forward_coarse: positional encoding enabled but pe is null");
   hipStream_t s = (hipStream_t)stream;
@@ -1270,7 +1270,12 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   size_t mark = a.off;
   const int hc = H / 8, wc = W / 8, L = hc * wc, C = ctx->cfg.coarse_d_model;
   bool forked = false;
-  if (ctx->cfg.fpn_overlap) {
+  if (!feat_f) {
+    // the caller runs no fine stage (fine_matching.enable = False): the fine map is not an output of the forward and nothing
+    // downstream reads it, so the FPN fine branch (x1_out; ~44 % of the backbone FLOPs) is not launched
+    BackboneBufs bufs;
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs));
+  } else if (ctx->cfg.fpn_overlap) {
     // The coarse level (tokens, transformer, matcher: many short launches that leave CUs idle) depends only on the
     // coarse map; the FPN fine branch (six chip-filling convolutions, ~40 % of the backbone FLOPs) is needed by the fine
     // stage only.  Run the fine branch on a side stream next to the coarse level: fork after layer3_outconv, join below.

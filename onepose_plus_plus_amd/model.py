@@ -180,6 +180,7 @@ class OnePosePlus_model(nn.Module):
         self.encoder_fusion = int(os.environ.get("OPP_ENCODER_FUSION", "2"))
         self.score_two_sweep = int(os.environ.get("OPP_SCORE_PATH", "2"))
         self.fpn_overlap = os.environ.get("OPP_FPN_OVERLAP", "1") != "0"
+        self.skip_unused_fine_map = os.environ.get("OPP_SKIP_UNUSED_FINE_MAP", "0") == "1"
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -236,6 +237,14 @@ class OnePosePlus_model(nn.Module):
             self.__del__()
             self.fpn_overlap = on
             self._reset_runtime()
+        return self
+
+    def set_skip_unused_fine_map(self, on):
+        """Opt-in (default off = the reference's operator list): with `fine_matching.enable = False` the fine feature map is
+        computed by the reference's backbone and then dropped (OnePosePlusModel.py:122-124, 169-176).  True: a B = 1 eval
+        forward does not launch the FPN branch that produces it (~44 % of the backbone FLOPs); every entry of `data` is
+        unchanged.  No effect while fine matching is enabled."""
+        self.skip_unused_fine_map = bool(on)
         return self
 
     def set_score_two_sweep(self, mode):
@@ -751,7 +760,9 @@ class OnePosePlus_model(nn.Module):
                 qscale = self._f32(data["query_image_scale"], "query_image_scale", device)
             pe = self._pe_tokens(hc, wc, device) if self.dense_pos_encoding is not None else None
 
-            feat_f = torch.empty((hf * wf, dF), dtype=torch.float32, device=device)     # NHWC fine map
+            feat_f = None                                                                # NHWC fine map
+            if cfg["fine_matching"]["enable"] or not getattr(self, "skip_unused_fine_map", False):
+                feat_f = torch.empty((hf * wf, dF), dtype=torch.float32, device=device)
             conf = torch.empty((1, N, L), dtype=torch.float32, device=device)
             i_ids = torch.empty(N, dtype=torch.int64, device=device)
             j_ids = torch.empty(N, dtype=torch.int64, device=device)
@@ -768,7 +779,7 @@ class OnePosePlus_model(nn.Module):
             _lib.check(lib.opp_forward_coarse(
                 ctx, img_c.data_ptr(), H, W, pe.data_ptr() if pe is not None else None, kpts.data_ptr(),
                 bank_c.data_ptr(), tok3d.data_ptr() if tok3d is not None else None, N, scale_c, qscale.data_ptr() if qscale is not None else None,
-                feat_f.data_ptr(), conf.data_ptr(), i_ids.data_ptr(), j_ids.data_ptr(), mconf.data_ptr(),
+                feat_f.data_ptr() if feat_f is not None else None, conf.data_ptr(), i_ids.data_ptr(), j_ids.data_ptr(), mconf.data_ptr(),
                 mk_c.data_ptr(), mk_3d.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), stream),
                 "opp_forward_coarse")
             with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):

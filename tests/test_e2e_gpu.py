@@ -564,3 +564,30 @@ def test_fine_branch_overlap_is_transparent():
         got = ops.run_model(on, data)
         for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f", "mkpts_query_c"):
             assert torch.equal(got[k], ref[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_skipping_the_unused_fine_map_changes_no_output(overlap):
+    """Coarse-only matching (`fine_matching.enable = False`, OnePosePlusModel.py:169-176: the reference computes the fine
+    map in its backbone and never reads it).  `set_skip_unused_fine_map(True)` hands `opp_forward_coarse` a NULL feat_f and
+    the FPN fine branch is not launched: every entry of `data` equals the run that computes the dead map, bit for bit; with
+    fine matching enabled the switch does nothing."""
+    import copy
+    from tests import hip_ops as ops
+    name = "highconf_512x512_n3000"
+    cfg, sd, data = H.highconf_setup(name)
+    coarse_cfg = copy.deepcopy(cfg)
+    coarse_cfg["fine_matching"]["enable"] = False
+    full = ops.make_model(coarse_cfg, sd, "bf16x3").set_fpn_overlap(overlap).cuda()
+    lean = ops.make_model(coarse_cfg, sd, "bf16x3").set_fpn_overlap(overlap).set_skip_unused_fine_map(True).cuda()
+    ref = ops.run_model(full, data)
+    assert len(ref["mconf"]) > 1000 and "expec_f" not in ref
+    for _ in range(2):
+        got = ops.run_model(lean, data)
+        assert set(got) == set(ref)
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "mkpts_query_c", "mkpts_query_f", "mkpts_3d_db"):
+            assert torch.equal(got[k], ref[k]), k
+    fine_on = ops.make_model(cfg, sd, "bf16x3").set_skip_unused_fine_map(True).cuda()
+    a, b = ops.run_model(fine_on, data), ops.run_model(ops.make_model(cfg, sd, "bf16x3"), data)
+    assert torch.equal(a["expec_f"], b["expec_f"]) and torch.equal(a["mkpts_query_f"], b["mkpts_query_f"])
