@@ -632,9 +632,12 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   const int hp = gemm_prec(c->cfg);
   if (phase != 2) {
-    // stem: conv7x7/s2 + BN + ReLU as im2col + GEMM (resnet.py:143)
-    OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
-    {
+    // stem: conv7x7/s2 + BN + ReLU (resnet.py:143): one direct kernel (bf16x3), else im2col + GEMM -- bit-identical
+    const char* stem_env = getenv("OPP_STEM_DIRECT");          // A/B switch of the tests / tools
+    if (opp_stem_direct_ok(c->stem.cout, hp) && pad32(c->stem.cout) == c->stem.cout && !(stem_env && stem_env[0] == '0')) {
+      OPP_TRY(opp_stem_direct(image, H, W, c->stem.w, c->stem.bias, b.x0, pad32(c->stem.cout), s));
+    } else {
+      OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
       OppGemm g;
       g.nonfinite = t_status_flag;
       g.tile_policy = t_tile_policy;

@@ -147,6 +147,9 @@ int opp_linattn_train_fwd(const float* q, const float* k, const float* v, const 
 int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const float* q_mask, const float* kv_mask, const float* kv, const float* ks,
                           const float* grad_out, int B, int L, int S, int H, int D, float eps, float* gq, float* gk, float* gv, void* ws,
                           size_t ws_bytes, hipStream_t stream);
+// stem_direct.hip -- 7x7 / stride 2 stem + bias + ReLU without the im2col matrix (bf16x3, 128 output channels)
+bool opp_stem_direct_ok(int cout, int prec);
+int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);

@@ -50,6 +50,25 @@ def test_backbone_shapes(small, hw):
     assert _rel(fc, rc) < 2e-5 and _rel(ff, rf) < 2e-5, (_rel(fc, rc), _rel(ff, rf))
 
 
+@pytest.mark.parametrize("hw", [(8, 8), (40, 72), (200, 328), (512, 512)])
+def test_direct_stem_is_bit_identical_to_im2col_gemm(hw):
+    """csrc/stem_direct.hip (7x7 / stride 2 stem + folded BatchNorm + ReLU in one kernel, no im2col matrix in memory;
+    backbone/resnet.py:101-103,143) against the im2col + GEMM path of the same arithmetic (OPP_STEM_DIRECT=0): the same
+    operand split and product order, so both feature maps agree bit for bit -- partial 8 x 16 pixel tiles included."""
+    import os
+    from tests import hip_ops as ops
+    cfg, sd, _ = H.e2e_setup("e2e_128x128_n300_thr0")
+    model = ops.make_model(cfg, sd, "bf16x3")
+    img = torch.rand(1, 1, hw[0], hw[1], generator=torch.Generator().manual_seed(hw[0] + 7 * hw[1]))
+    fc, ff = ops.backbone(model, img)
+    os.environ["OPP_STEM_DIRECT"] = "0"
+    try:
+        rc, rf = ops.backbone(model, img)
+    finally:
+        del os.environ["OPP_STEM_DIRECT"]
+    assert torch.equal(fc, rc) and torch.equal(ff, rf)
+
+
 def test_tokens_and_transformer(small):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops
