@@ -104,16 +104,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_kernel(const OppGemmSS g) {
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
 
-  // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only): contiguous tile ranges per XCD, the column tiles of one
-  // row panel adjacent, so that an XCD's L2 keeps its A panels
-  const int tiles_n = (g.N + BN - 1) / BN;
+  // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only -- every output is indexed by tile coordinates): an XCD gets
+  // a contiguous range of a linear order that walks STRIPS of RS row panels column by column (row fastest).  The ~64 tiles an
+  // XCD has in flight then cover RS row panels x 8 column panels = 16 operand panels of 192 KB (3 MB of its 4 MB L2), every
+  // column panel is fetched once per strip and XCD instead of once per row panel: 227 -> MB of fetches per
+  // launch at 4096 x 5000 (row-major order: each XCD streamed all 40 column panels four times).
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   int tile_lin = blockIdx.x;
   {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     tile_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_m = tile_lin / tiles_n, tile_n = tile_lin - tile_m * tiles_n;
+  constexpr int RS = 8;
+  const int strip = tile_lin / (RS * tiles_n);
+  const int within = tile_lin - strip * (RS * tiles_n);
+  const int strip_rows = min(RS, tiles_m - strip * RS);
+  const int tile_n = within / strip_rows;
+  const int tile_m = strip * RS + (within - tile_n * strip_rows);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- LDS-DMA slots: instruction n of a tile covers linear pieces [64 n, 64 n + 64) of the [rows][6] image --------
