@@ -119,8 +119,12 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the other-arithmetic and fine-stage legs")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "fp16x2", "fp16x2_all"],
                     help="GEMM arithmetic (default: the module default bf16x3 / OPP_GEMM_PRECISION)")
-    ap.add_argument("--tile-policy", default="latency", choices=["latency", "throughput"],
-                    help="automatic GEMM / conv tile choice for the headline (see opp_config.tile_policy)")
+    ap.add_argument("--tile-policy", default="auto", choices=["auto", "latency", "throughput"],
+                    help="automatic GEMM / conv tile choice (opp_config.tile_policy); auto = what serving.MatcherPool uses: "
+                         "throughput with several forwards in flight, latency for one")
+    ap.add_argument("--fpn-overlap", default="auto", choices=["auto", "on", "off"],
+                    help="FPN fine branch on a side HIP stream (opp_config.fpn_overlap); auto = on for one forward in flight, off for "
+                         "several (the other forwards are the overlap; extra streams only crowd the hardware queues)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPP_BENCH_STREAMS", "3")),
                     help="B=1 forwards kept in flight per GPU on separate HIP streams (the reference runs "
                          "2 Ray workers per GPU, inference_OnePosePlus.py:18-26)")
@@ -203,14 +207,19 @@ def run(args):
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
-    # tile choice (opp_config.tile_policy): the headline and its roofline use the per-launch-latency tiles, whose kernels
-    # fill the chip on their own, so a symbol's stand-alone duration is a meaningful roofline figure; the least-CU-time
-    # tiles that serving.MatcherPool uses with several forwards in flight are reported as `config.throughput_tiles_leg`
-    policy = args.tile_policy
-    model.set_tile_policy(policy)
+    # scheduling switches (bit-identical results either way), set the way serving.MatcherPool sets them: with several forwards
+    # in flight the least-CU-time tiles (other forwards' kernels take the CUs a launch leaves idle) and no side streams inside
+    # a forward; for one forward in flight the per-launch-latency tiles and the fine branch of the backbone on a side stream.
+    # Measured at 3 streams (tools/ab_queues.sh): 491 (latency tiles) -> 512 (throughput tiles) images/s, side streams -0.7 / -3 %;
+    # the other tile policy is reported as a leg.
+    policy = args.tile_policy if args.tile_policy != "auto" else ("throughput" if n_streams > 1 else "latency")
+    overlap = (n_streams == 1) if args.fpn_overlap == "auto" else args.fpn_overlap == "on"
+    if args.fpn_overlap == "auto" and "OPP_FPN_OVERLAP" in os.environ:
+        overlap = os.environ["OPP_FPN_OVERLAP"] != "0"
+    model.set_tile_policy(policy).set_fpn_overlap(overlap)
     models = [model]
     for _ in range(1, n_streams):        # one module (own workspace / outputs) per in-flight forward
-        m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).set_tile_policy(policy).to(dev)
+        m = OnePosePlus_model(cfg).eval().set_gemm_precision(precision).set_tile_policy(policy).set_fpn_overlap(overlap).to(dev)
         m.load_state_dict(model.state_dict(), strict=True)
         models.append(m)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
@@ -314,14 +323,13 @@ def run(args):
     if prof:
         # a kernel's own duration: one forward in flight AND the FPN fine branch on the same stream (with opp_config.fpn_overlap
         # the coarse-level kernels share the CUs with the fine-branch convolutions and every launch of both stretches)
-        overlap = [getattr(m, "fpn_overlap", True) for m in models]
         for m in models:
             m.set_fpn_overlap(False).to(dev)
         step(0, 0)
         torch.cuda.synchronize(dev)
         roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps * ips, 20))
-        for m, o in zip(models, overlap):
-            m.set_fpn_overlap(o).to(dev)
+        for m in models:
+            m.set_fpn_overlap(overlap).to(dev)
         for k in range(n_streams):
             step(0, k)
         torch.cuda.synchronize(dev)
@@ -357,7 +365,7 @@ def run(args):
                                    % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", ips, n_streams,
                                       args.thr, matches_last),
                        "images_per_step": ips, "streams_per_gpu": n_streams,
-                       "per_rank_images_per_s": {"min": min(per_rank), "max": max(per_rank), "sum": round(sum(per_rank), 2)}, "gemm_precision": precision, "tile_policy": policy,
+                       "per_rank_images_per_s": {"min": min(per_rank), "max": max(per_rank), "sum": round(sum(per_rank), 2)}, "gemm_precision": precision, "tile_policy": policy, "fpn_overlap": bool(overlap),
                        "matches_last_step": matches_last, "object_token_cache": True,
                        "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
@@ -378,9 +386,10 @@ def compact_legs(legs):
     oa = legs.get("other_arithmetics") or {}
     if oa:
         out["other_arithmetics_images_per_s"] = {k: v.get("value") for k, v in oa.items()}
-    t = legs.get("throughput_tiles_leg")
-    if t:
-        out["throughput_tiles_images_per_s"] = t.get("value")
+    for pol in ("throughput", "latency"):
+        t = legs.get(pol + "_tiles_leg")
+        if t:
+            out[pol + "_tiles_images_per_s"] = t.get("value")
     t = legs.get("coarse_only_without_unused_fine_map_leg")
     if t:
         out["coarse_only_without_unused_fine_map_images_per_s"] = t.get("value")
@@ -491,7 +500,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
         for k in range(n_streams):
             step(0, k)
         torch.cuda.synchronize(dev)
-        n = min(args.steps * max(1, args.images_per_step), 48)
+        n = min(args.steps * max(1, args.images_per_step), 240)     # >= 0.5 s: the start-up of run_steps' host threads is a few ms each
         t1 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize(dev)
@@ -501,22 +510,25 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
     for m in models:
         m.set_gemm_precision(precision).to(dev)
     legs["other_arithmetics"] = other
-    if n_streams > 1 and args.tile_policy == "latency":
-        # the same workload with the tiles chosen for least CU time (what MatcherPool runs with several forwards in flight)
+    policy = getattr(models[0], "tile_policy", "latency")
+    if n_streams > 1:
+        # the same workload with the other tile policy (bit-identical results): latency = every launch sized to fill the chip on
+        # its own, throughput = least CU time per launch
+        other_policy = "latency" if policy == "throughput" else "throughput"
         for m in models:
-            m.set_tile_policy("throughput").to(dev)
+            m.set_tile_policy(other_policy).to(dev)
         for k in range(n_streams):
             step(0, k)
         torch.cuda.synchronize(dev)
         run_steps(2 * n_streams)
-        n = min(args.steps * max(1, args.images_per_step), 96)
+        n = min(args.steps * max(1, args.images_per_step), 320)
         t1 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize(dev)
-        legs["throughput_tiles_leg"] = {"value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
-                                        "note": "opp_config.tile_policy = 1: bit-identical results, fewer / larger tiles per launch"}
+        legs["%s_tiles_leg" % other_policy] = {"value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
+                                               "note": "opp_config.tile_policy = %s instead of %s" % (other_policy, policy)}
         for m in models:
-            m.set_tile_policy("latency").to(dev)
+            m.set_tile_policy(policy).to(dev)
     if not args.fine:
         # the same coarse-only workload without the fine feature map nothing reads (model.set_skip_unused_fine_map: an opt-in
         # dead-branch elimination the reference cannot do; NOT the headline, which launches every operator of the reference)
@@ -526,7 +538,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
             step(0, k)
         torch.cuda.synchronize(dev)
         run_steps(2 * n_streams)
-        n = min(args.steps * max(1, args.images_per_step), 96)
+        n = min(args.steps * max(1, args.images_per_step), 320)
         t1 = time.perf_counter()
         run_steps(n)
         torch.cuda.synchronize(dev)

@@ -27,6 +27,7 @@ class MatcherPool:
                 m.set_gemm_precision(gemm_precision)
             if int(n_streams) > 1:
                 m.set_tile_policy("throughput")      # several forwards share the chip: tiles chosen for least CU time
+                m.set_fpn_overlap(False)             # ... and they are each other's overlap: no side streams inside a forward
             m.load_state_dict(state_dict, strict=True)
             self.models.append(m.to(self.device))
             self.streams.append(torch.cuda.Stream(device=self.device))

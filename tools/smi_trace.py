@@ -8,7 +8,9 @@ Two samplers next to the child process:
     starred line of pp_dpm_sclk -- whatever of these the driver exposes for the first amdgpu card;
   * `amd-smi metric --clock --power --usage --json` (falls back to `rocm-smi --showclocks --showpower --json`), once a second.
 Writes <out>.sysfs.csv, <out>.smi.jsonl and <out>.summary.json (min / mean / max of every sampled quantity over the part of
-the run in which the GPU was busy: sclk above the idle level).
+the run in which the GPU was busy).  The amd-smi samples (`amd_smi` in the summary: gfx activity, socket power, per-XCD gfx
+clocks of the one GPU the box exposes) are the authoritative ones; sysfs card0 is not necessarily the GPU in use on a multi-GPU
+host.
 """
 import argparse
 import glob
@@ -63,7 +65,58 @@ def starred_mhz(text):
     return None
 
 
+def smi_rows(lines):
+    """amd-smi metric --json samples -> [{t, gfx_activity_pct, socket_power_w, gfx_clk_mhz_mean / min / max over the XCDs}] of GPU 0
+    (the one GPU the box exposes)"""
+    out = []
+    for ln in lines:
+        try:
+            rec = json.loads(ln)
+            gpu = json.loads(rec["out"])
+            gpu = (gpu.get("gpu_data") if isinstance(gpu, dict) else gpu)[0]
+        except (ValueError, KeyError, IndexError, TypeError):
+            continue
+        row = {"t": round(rec.get("t", 0.0), 3)}
+        try:
+            row["gfx_activity_pct"] = float(gpu["usage"]["gfx_activity"]["value"])
+        except (KeyError, TypeError, ValueError):
+            pass
+        try:
+            row["socket_power_w"] = float(gpu["power"]["socket_power"]["value"])
+        except (KeyError, TypeError, ValueError):
+            pass
+        clks = []
+        for k, v in (gpu.get("clock") or {}).items():
+            if k.startswith("gfx_"):
+                try:
+                    clks.append(float(v["clk"]["value"]))
+                except (KeyError, TypeError, ValueError):
+                    pass
+        if clks:
+            row.update({"gfx_clk_mhz_mean": sum(clks) / len(clks), "gfx_clk_mhz_min": min(clks), "gfx_clk_mhz_max": max(clks), "xcds": len(clks)})
+            try:
+                row["gfx_clk_mhz_limit"] = float(next(iter(gpu["clock"].values()))["max_clk"]["value"])
+            except (KeyError, TypeError, ValueError, StopIteration):
+                pass
+        out.append(row)
+    return out
+
+
+def smi_summary(rows):
+    busy = [r for r in rows if r.get("gfx_activity_pct", 0) >= 50]
+    s = {"samples": len(rows), "busy_samples (gfx_activity >= 50 %)": len(busy)}
+    for k in ("gfx_activity_pct", "socket_power_w", "gfx_clk_mhz_mean", "gfx_clk_mhz_min", "gfx_clk_mhz_max", "gfx_clk_mhz_limit"):
+        v = [r[k] for r in busy if k in r]
+        if v:
+            s[k] = {"min": min(v), "mean": round(sum(v) / len(v), 1), "max": max(v)}
+    return s
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--summarize":      # offline: tools/smi_trace.py --summarize <out>.smi.jsonl
+        rows = smi_rows(open(sys.argv[2]).read().splitlines())
+        print(json.dumps({"amd_smi": smi_summary(rows), "rows": rows}, indent=1))
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--period", type=float, default=0.05)
@@ -111,7 +164,7 @@ def main():
                         break
                 except (OSError, subprocess.TimeoutExpired):
                     pass
-            stop.wait(1.0)
+            stop.wait(0.25)
 
     th = [threading.Thread(target=sysfs_loop, daemon=True), threading.Thread(target=smi_loop, daemon=True)]
     for t in th:
@@ -140,9 +193,12 @@ def main():
             v = [r[k] for r in busy if k in r]
             if v:
                 summary[k] = {"min": min(v), "mean": sum(v) / len(v), "max": max(v)}
+    srows = smi_rows(smi_lines)
+    summary["amd_smi"] = smi_summary(srows)
+    summary["amd_smi_rows"] = srows
     with open(a.out + ".summary.json", "w") as f:
         json.dump(summary, f, indent=1)
-    print(json.dumps({k: v for k, v in summary.items() if k not in ("sources", "command")}))
+    print(json.dumps({k: v for k, v in summary.items() if k not in ("sources", "command", "amd_smi_rows")}))
     return rc
 
 
