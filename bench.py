@@ -119,9 +119,8 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the other-arithmetic and fine-stage legs")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "fp16x2", "fp16x2_all"],
                     help="GEMM arithmetic (default: the module default bf16x3 / OPP_GEMM_PRECISION)")
-    ap.add_argument("--tile-policy", default="auto", choices=["auto", "latency", "throughput"],
-                    help="automatic GEMM / conv tile choice (opp_config.tile_policy); auto = what serving.MatcherPool uses: "
-                         "throughput with several forwards in flight, latency for one")
+    ap.add_argument("--tile-policy", default="latency", choices=["latency", "throughput"],
+                    help="automatic GEMM / conv tile choice for the headline (opp_config.tile_policy); the other one is reported as a leg")
     ap.add_argument("--fpn-overlap", default="auto", choices=["auto", "on", "off"],
                     help="FPN fine branch on a side HIP stream (opp_config.fpn_overlap); auto = on for one forward in flight, off for "
                          "several (the other forwards are the overlap; extra streams only crowd the hardware queues)")
@@ -207,12 +206,13 @@ def run(args):
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
-    # scheduling switches (bit-identical results either way), set the way serving.MatcherPool sets them: with several forwards
-    # in flight the least-CU-time tiles (other forwards' kernels take the CUs a launch leaves idle) and no side streams inside
-    # a forward; for one forward in flight the per-launch-latency tiles and the fine branch of the backbone on a side stream.
-    # Measured at 3 streams (tools/ab_queues.sh): 491 (latency tiles) -> 512 (throughput tiles) images/s, side streams -0.7 / -3 %;
-    # the other tile policy is reported as a leg.
-    policy = args.tile_policy if args.tile_policy != "auto" else ("throughput" if n_streams > 1 else "latency")
+    # scheduling switches (bit-identical results either way).  Tiles: the headline and its roofline use the per-launch-latency
+    # tiles, whose kernels fill the chip on their own, so a symbol's stand-alone duration is a meaningful roofline figure; the
+    # least-CU-time tiles serving.MatcherPool uses with several forwards in flight (other forwards' kernels take the CUs a launch
+    # leaves idle; 491 -> 512 images/s at 3 streams, tools/ab_queues.sh) are reported as `throughput_tiles_leg`.  Side stream of
+    # the FPN fine branch: on for one forward in flight, off for several (the other forwards are the overlap; more streams only
+    # crowd the hardware queues: -0.7 % with the latency tiles, -3 % with the throughput tiles).
+    policy = args.tile_policy
     overlap = (n_streams == 1) if args.fpn_overlap == "auto" else args.fpn_overlap == "on"
     if args.fpn_overlap == "auto" and "OPP_FPN_OVERLAP" in os.environ:
         overlap = os.environ["OPP_FPN_OVERLAP"] != "0"

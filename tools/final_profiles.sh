@@ -2,7 +2,7 @@
 # Order matters: the PMC passes come first, their summary is what bench.py's roofline leg reads as `traffic`.
 set -x
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_bench.sh gpurun_out/final_pmc --tile-policy throughput
+bash tools/pmc_bench.sh gpurun_out/final_pmc
 python tools/pmc_traffic_summary.py gpurun_out/final_pmc gpurun_out/final_pmc_traffic.csv profiles/traffic_symbols_bf16x3.json > /dev/null
 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_default.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_driver.json 2> gpurun_out/final_bench_driver.err
@@ -10,7 +10,7 @@ python tools/smi_trace.py --out gpurun_out/final_smi -- python bench.py --steps 
 python tools/train_probe.py > gpurun_out/final_train_probe.txt 2> gpurun_out/final_train_probe.err
 cd /tmp && export TMPDIR=/tmp
 # single stream, fine branch on the same stream, the tiles of the timed region: the condition of bench.py's roofline pass
-OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 --tile-policy throughput > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
+OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --images-per-step 1 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_fine -o fine -- python $GRAFT_REPO_ROOT/tools/fine_profile.py > $GRAFT_REPO_ROOT/gpurun_out/final_fine.log 2>&1
 cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv
