@@ -15,11 +15,14 @@ constexpr int TY = 8, TX = 16, ROWS = TY * TX, KP = 64, COUT = 128;
 constexpr int SA = a_stride_bytes(KP);                 // 400
 constexpr int PH = 2 * TY + 5, PW = 2 * TX + 5, PWS = 40;
 constexpr int WROW = KP * 6;                           // bytes per pre-split weight row (opp_pack_b3 layout)
+constexpr int CS = COUT + 4;                           // staged output row stride (floats)
+static_assert(ROWS * CS * 4 >= ROWS * SA, "the output tile reuses the operand space");
 
 __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restrict__ img, int H, int W, int Ho, int Wo,
                                                           const char* __restrict__ wsplit, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ldc) {
-  __shared__ __attribute__((aligned(16))) char A[ROWS * SA];
+  // operand rows [128][400 B]; after the MFMAs the same space stages the output tile [128][CS floats] for 512-byte row stores
+  __shared__ __attribute__((aligned(16))) char A[ROWS * CS * 4];
   __shared__ float patch[PH * PWS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restric
                                                                acc[i][j], 0, 0, 0);
   }
 
-  // bias (BatchNorm folded), ReLU; a lane holds one channel of 16 pixels per block: 32 lanes = 128 contiguous bytes of a pixel row
+  // bias (BatchNorm folded), ReLU, then through LDS so that a pixel's 128 channels leave as one 512-byte row (16 B per lane)
+  __syncthreads();          // every wave is done reading the operand rows
+  float* Ct = reinterpret_cast<float*>(A);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wn * 64 + j * 32 + l31;
@@ -96,12 +101,20 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int ly = lr / TX, lx = lr - ly * TX;
-        const int oy = oy0 + ly, ox = ox0 + lx;
         float v = acc[i][j][r] + bv;
         v = v < 0.f ? 0.f : v;   // NaN-propagating like torch.relu
-        if (oy < Ho && ox < Wo) out[((size_t)oy * Wo + ox) * ldc + col] = v;
+        Ct[lr * CS + col] = v;
       }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ROWS * (COUT / 4) / 256; ++it) {
+    const int u = tid + it * 256;
+    const int lr = u / (COUT / 4), c4 = (u - lr * (COUT / 4)) * 4;
+    const int ly = lr / TX, lx = lr - ly * TX;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy < Ho && ox < Wo)
+      *reinterpret_cast<float4*>(out + ((size_t)oy * Wo + ox) * ldc + c4) = *reinterpret_cast<const float4*>(Ct + lr * CS + c4);
   }
 }
 
@@ -111,7 +124,8 @@ bool opp_stem_direct_ok(int cout, int prec) { return cout == COUT && prec == OPP
 
 int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream) {
   OPP_CHECK_ARG(img && wsplit && bias && out && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldc >= COUT, "stem_direct: bad argument");
-  OPP_CHECK_ARG((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0, "stem_direct: weights must be 16-byte aligned");
+  OPP_CHECK_ARG((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ldc % 4 == 0,
+                "stem_direct: weights / output must be 16-byte aligned, ldc a multiple of 4");
   const int Ho = H / 2, Wo = W / 2;
   OPP_CHECK_ARG((size_t)Ho * Wo * ldc < (1ull << 31), "stem_direct: output too large for 32-bit indexing");
   hipLaunchKernelGGL(stem_direct_kernel, dim3(opp_cdiv(Wo, TX), opp_cdiv(Ho, TY)), dim3(256), 0, stream, img, H, W, Ho, Wo,
