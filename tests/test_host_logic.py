@@ -133,3 +133,32 @@ def test_gemm_precision_selector(monkeypatch):
     monkeypatch.setenv("OPP_GEMM_PRECISION", "tf32")
     with pytest.raises(ValueError):
         OnePosePlus_model(default_config())._c_config()
+
+
+def test_scheduling_switches(monkeypatch):
+    """Host side of the scheduling switches (results are bit-identical for every value; GPU tests check that): defaults, setters,
+    `opp_config` fields, env overrides, pickling, bad values."""
+    import pickle
+    for k in ("OPP_ENCODER_FUSION", "OPP_SCORE_PATH", "OPP_FPN_OVERLAP", "OPP_SKIP_UNUSED_FINE_MAP"):
+        monkeypatch.delenv(k, raising=False)
+    m = OnePosePlus_model(default_config())
+    c = m._c_config()
+    assert (c.encoder_fusion, c.score_two_sweep, c.fpn_overlap, c.tile_policy) == (2, 2, 1, 0)
+    assert m.skip_unused_fine_map is False                       # the default launches every operator of the reference
+    m.set_encoder_fusion(1).set_score_two_sweep(0).set_fpn_overlap(False).set_tile_policy("throughput").set_skip_unused_fine_map(True)
+    c = m._c_config()
+    assert (c.encoder_fusion, c.score_two_sweep, c.fpn_overlap, c.tile_policy) == (1, 0, 0, 1)
+    m2 = pickle.loads(pickle.dumps(m))                           # the switches travel with the module
+    c2 = m2._c_config()
+    assert (c2.encoder_fusion, c2.score_two_sweep, c2.fpn_overlap, c2.tile_policy, m2.skip_unused_fine_map) == (1, 0, 0, 1, True)
+    for bad in (lambda: m.set_encoder_fusion(3), lambda: m.set_score_two_sweep(5), lambda: m.set_tile_policy("fastest")):
+        with pytest.raises(ValueError):
+            bad()
+    monkeypatch.setenv("OPP_ENCODER_FUSION", "0")
+    monkeypatch.setenv("OPP_SCORE_PATH", "1")
+    monkeypatch.setenv("OPP_FPN_OVERLAP", "0")
+    monkeypatch.setenv("OPP_SKIP_UNUSED_FINE_MAP", "1")
+    e = OnePosePlus_model(default_config())
+    c = e._c_config()
+    assert (c.encoder_fusion, c.score_two_sweep, c.fpn_overlap, e.skip_unused_fine_map) == (0, 1, 0, True)
+
