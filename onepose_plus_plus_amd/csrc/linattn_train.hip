@@ -267,6 +267,7 @@ int opp_linattn_train_fwd(const float* q, const float* k, const float* v, const 
                           float eps, float* out, float* kv, float* ks, void* ws, size_t ws_bytes, hipStream_t stream) {
   OPP_CHECK_ARG(q && k && v && out && kv && ks && ws && B > 0 && L > 0 && S > 0 && H > 0, "linattn_train: null / empty argument");
   OPP_CHECK_ARG(D == 32 || D == 16, "linattn_train: head width must be 32 or 16 (got %d)", D);
+  OPP_CHECK_ARG(B <= 65535 && H <= 65535, "linattn_train: batch %d / heads %d exceed the grid limit of 65535", B, H);
   OPP_CHECK_ARG(ws_bytes >= opp_linattn_train_ws_bytes(B, L, S, H, D), "linattn_train: workspace too small");
   return D == 32 ? fwd_impl<32>(q, k, v, q_mask, kv_mask, B, L, S, H, eps, out, kv, ks, static_cast<float*>(ws), stream)
                  : fwd_impl<16>(q, k, v, q_mask, kv_mask, B, L, S, H, eps, out, kv, ks, static_cast<float*>(ws), stream);
@@ -277,6 +278,7 @@ int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const 
                           size_t ws_bytes, hipStream_t stream) {
   OPP_CHECK_ARG(q && k && v && kv && ks && grad_out && gq && gk && gv && ws && B > 0 && L > 0 && S > 0 && H > 0, "linattn_train backward: null / empty argument");
   OPP_CHECK_ARG(D == 32 || D == 16, "linattn_train backward: head width must be 32 or 16 (got %d)", D);
+  OPP_CHECK_ARG(B <= 65535 && H <= 65535, "linattn_train backward: batch %d / heads %d exceed the grid limit of 65535", B, H);
   OPP_CHECK_ARG(ws_bytes >= opp_linattn_train_ws_bytes(B, L, S, H, D), "linattn_train backward: workspace too small");
   return D == 32 ? bwd_impl<32>(q, k, v, q_mask, kv_mask, kv, ks, grad_out, B, L, S, H, eps, gq, gk, gv, static_cast<float*>(ws), stream)
                  : bwd_impl<16>(q, k, v, q_mask, kv_mask, kv, ks, grad_out, B, L, S, H, eps, gq, gk, gv, static_cast<float*>(ws), stream);

@@ -183,7 +183,7 @@ def _kpt_encoding(p, kpts, desc):
 
 
 def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loftr_module/linear_attention.py:29-61
-    if _HIP_LINEAR_PREC is not None and q.is_cuda and q.shape[-1] in (16, 32) and eps == 1e-6:
+    if _HIP_LINEAR_PREC is not None and q.is_cuda and q.shape[-1] in (16, 32) and eps == 1e-6 and q.shape[0] <= 65535:   # (grid.z = sample)
         return HipLinearAttention.apply(q, k, v, q_mask, kv_mask)
     Q, K = F.elu(q) + 1, F.elu(k) + 1
     if q_mask is not None:
