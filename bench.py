@@ -559,7 +559,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
     return legs
 
 
-def train_leg(torch, dev, precision, nsteps=2):
+def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
     """One training step at the per-GPU shape of BASELINE configs[4] (B = 4, 512x512, N = 7000 points padded as the
     reference's dataset does, train.yaml:185,194): train()-mode forward on the HIP path (BatchNorm batch statistics,
     training branch of get_coarse_match, fine level on the padded matches), `fine_supervision` + `Loss` of this package
@@ -629,6 +629,11 @@ def train_leg(torch, dev, precision, nsteps=2):
 
     fwd_ms, _ = timed(fwd_only)
     step_ms, loss = timed(full_step)
+    if step_profiler is not None:            # tools/train_probe.py: a profiler context around warmed-up steps only
+        with step_profiler:
+            for _ in range(nsteps):
+                full_step()
+            torch.cuda.synchronize(dev)
     loss_only()
     focal_ms = min(loss_only() for _ in range(3))
     n_conf = B * N * 4096

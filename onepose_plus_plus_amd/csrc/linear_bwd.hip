@@ -53,7 +53,8 @@ struct Plan {
 Plan make_plan(int M, int N, int K, int prec) {
   Plan p;
   const int tiles = opp_cdiv(N, 128) * opp_cdiv(K, 128);
-  int splits = 512 / (tiles > 0 ? tiles : 1);               // ~ two workgroups' worth of tiles per CU
+  int splits = 256 / (tiles > 0 ? tiles : 1);               // one workgroup per CU (the 8-wave 128 x 128 tile owns a CU): one round,
+                                                             // and half the partial-sum traffic of two half-length rounds
   const int chunks = opp_cdiv(M, 32);
   if (splits > chunks / 4) splits = chunks / 4;              // >= 4 chunks of 32 tokens per split
   if (splits < 1) splits = 1;
