@@ -162,3 +162,30 @@ def test_scheduling_switches(monkeypatch):
     c = e._c_config()
     assert (c.encoder_fusion, c.score_two_sweep, c.fpn_overlap, e.skip_unused_fine_map) == (0, 1, 0, True)
 
+
+
+def test_smi_trace_summary_reads_amd_smi_samples():
+    """tools/smi_trace.py (clock / power evidence beside a bench run): the amd-smi JSON samples are reduced to activity, socket
+    power and per-XCD gfx clocks over the busy part of the run; malformed samples are skipped."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("smi_trace", os.path.join(root, "tools", "smi_trace.py"))
+    smi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(smi)
+
+    def sample(t, act, watts, clocks):
+        gpu = {"gpu": 0, "usage": {"gfx_activity": {"value": act, "unit": "%"}}, "power": {"socket_power": {"value": watts, "unit": "W"}},
+               "clock": {"gfx_%d" % i: {"clk": {"value": c, "unit": "MHz"}, "max_clk": {"value": 2400, "unit": "MHz"}} for i, c in enumerate(clocks)}}
+        gpu["clock"]["mem_0"] = {"clk": {"value": 2000, "unit": "MHz"}}
+        return json.dumps({"t": t, "tool": "amd-smi", "out": json.dumps({"gpu_data": [gpu]})})
+
+    lines = [sample(0.1, 0, 250, [150] * 8), sample(1.0, 100, 1380, [2000, 2100] * 4), sample(2.0, 98, 1360, [2050] * 8), "not json",
+             json.dumps({"t": 3.0, "tool": "amd-smi", "out": "{}"})]
+    rows = smi.smi_rows(lines)
+    assert len(rows) == 3 and rows[1]["xcds"] == 8 and rows[1]["gfx_clk_mhz_mean"] == 2050.0 and rows[1]["gfx_clk_mhz_limit"] == 2400.0
+    s = smi.smi_summary(rows)
+    assert s["samples"] == 3 and s["busy_samples (gfx_activity >= 50 %)"] == 2
+    assert s["socket_power_w"] == {"min": 1360.0, "mean": 1370.0, "max": 1380.0}
+    assert s["gfx_clk_mhz_mean"]["mean"] == 2050.0 and s["gfx_clk_mhz_min"]["min"] == 2000.0
