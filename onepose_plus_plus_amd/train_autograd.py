@@ -201,9 +201,20 @@ def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loft
 def _encoder_layer(p, name, nhead, x, source, x_mask=None, source_mask=None):      # loftr_module/transformer.py:65-94
     B, _, C = x.shape
     D = C // nhead
-    q = _linear(x, p[name + ".q_proj.weight"]).view(B, -1, nhead, D)
-    k = _linear(source, p[name + ".k_proj.weight"]).view(B, -1, nhead, D)
-    v = _linear(source, p[name + ".v_proj.weight"]).view(B, -1, nhead, D)
+    wq, wk, wv = p[name + ".q_proj.weight"], p[name + ".k_proj.weight"], p[name + ".v_proj.weight"]
+    if _HIP_LINEAR_PREC is not None and x.is_cuda:
+        # projections that read the same tokens run as ONE Linear node on the stacked weight: its backward transposes / splits
+        # the shared input once and reduces one [2C | 3C] x C weight gradient instead of two or three C x C ones
+        if source is x:
+            q, k, v = _linear(x, torch.cat([wq, wk, wv], 0)).split(C, dim=2)
+        else:
+            q = _linear(x, wq)
+            k, v = _linear(source, torch.cat([wk, wv], 0)).split(C, dim=2)
+        q, k, v = (t.reshape(B, -1, nhead, D) for t in (q, k, v))
+    else:
+        q = _linear(x, wq).view(B, -1, nhead, D)
+        k = _linear(source, wk).view(B, -1, nhead, D)
+        v = _linear(source, wv).view(B, -1, nhead, D)
     msg = _linear_attention(q, k, v, x_mask, source_mask).reshape(B, -1, C)
     msg = F.layer_norm(_linear(msg, p[name + ".merge.weight"]), (C,), p[name + ".norm1.weight"], p[name + ".norm1.bias"], _EPS_LN)
     msg = _linear(F.relu(_linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"])), p[name + ".mlp.2.weight"])
