@@ -482,7 +482,17 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     if not meas:
         return None
     meas.sort(key=lambda m: -m["us_per_forward"])
-    roof = meas[0]
+    # the line stays short enough for log tails: strings every entry shares are kept once, on the dominant kernel's entry
+    src = None
+    for m in meas:
+        for t in ([m["traffic"]] if isinstance(m["traffic"], dict) and "per_launch_shape" not in m["traffic"] else
+                  list(m["traffic"]["per_launch_shape"].values()) if isinstance(m["traffic"], dict) else []):
+            src = t.pop("source", None) or src
+    for m in meas[1:]:
+        m.pop("measured", None)
+    roof = dict(meas[0])
+    if src:
+        roof["traffic_source"] = src
     roof["other_kernels"] = meas[1:]
     return roof
 
