@@ -262,6 +262,70 @@ int opp_linear_attention_train_backward(const float* q, const float* k, const fl
                                         float* grad_q, float* grad_k, float* grad_v, void* workspace, size_t workspace_bytes,
                                         void* stream);
 
+/* ---- training step: ResNet-FPN forward that keeps its activations, and its backward ---------------------------------------
+ * PL_OnePosePlus.training_step (src/lightning_model/OnePosePlus_lightning_model.py:54-81) differentiates the loss through
+ * ResNetFPN_8_2.forward (backbone/resnet.py:141-164): nn.Conv2d (no bias), nn.BatchNorm2d in train(), ReLU / LeakyReLU(0.01),
+ * the residual adds and the two bilinear x2 upsamples.  opp_backbone_train_tape is opp_backbone_train writing every tensor the
+ * backward needs (raw convolution outputs, block outputs, batch mean / 1/sqrt(var + eps) per BatchNorm) into the caller's
+ * `tape` (nothing is recomputed later); opp_backbone_backward takes the gradients of the two outputs, feat_c [B][H/8][W/8][256]
+ * and feat_f [B][H/2][W/2][128] (NHWC), and writes the gradient of EVERY backbone parameter: `weights` is the table given to
+ * opp_pack_weights (the raw convolution weights are read from it), grads[i] the device pointer that receives the gradient of
+ * weights[i] in the PyTorch layout ([cout][cin][kh][kw]; BatchNorm weight / bias [C]); entries of tensors outside the backbone
+ * and of the running statistics are ignored and may be NULL.  Convolution input gradients run on the implicit-GEMM kernel with
+ * the flipped / transposed weight, weight gradients on a pixel-major split reduction (csrc/conv_bwd.hip), in the arithmetic of
+ * opp_config.gemm_precision (3 = bf16x3 or 0 = fp32; the weight-gradient kernel is bf16x3 in both: operands exact, fp32 accumulate). */
+size_t opp_backbone_tape_bytes(const opp_ctx* ctx, int B, int H, int W);
+size_t opp_backbone_train_tape_workspace_bytes(const opp_ctx* ctx, int B, int H, int W);
+int opp_backbone_train_tape(opp_ctx* ctx, const float* image, int B, int H, int W, float* feat_c, float* feat_f, float* bn_stats,
+                            void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, void* stream);
+size_t opp_backbone_backward_workspace_bytes(const opp_ctx* ctx, int B, int H, int W);
+int opp_backbone_backward(opp_ctx* ctx, const float* image, int B, int H, int W, const void* tape, size_t tape_bytes,
+                          const float* const* weights, int n_weights, const float* grad_feat_c, const float* grad_feat_f,
+                          float* const* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of one nn.Conv2d (bias-free, kernel 1 or 3, padding k/2, stride 1 or 2; backbone/resnet.py:10-18) over NHWC tensors
+ * whose channel counts are padded to multiples of 32 with zeros: x [B][Hin][Win][cin_pad], w [cout][cin][ks][ks] (PyTorch layout),
+ * grad_y [B][Ho][Wo][cout_pad].  grad_x [B][Hin][Win][cin_pad] and / or grad_w [cout][cin][ks][ks] (either may be NULL).
+ * prec 0 = fp32 MFMA, 2 = bf16x3. */
+size_t opp_conv2d_backward_workspace_bytes(int B, int Hin, int Win, int cin, int cout, int ks, int stride, int prec);
+int opp_conv2d_backward_nhwc(const float* x, int B, int Hin, int Win, int cin, const float* w, int cout, int ks, int stride,
+                             const float* grad_y, float* grad_x, float* grad_w, int prec, void* workspace, size_t workspace_bytes,
+                             void* stream);
+/* Backward of nn.BatchNorm2d in train() followed by (+ residual) -> activation (backbone/resnet.py:25-26, :37-45) over an NHWC
+ * tensor [rows][ld] with C real channels: y = act((raw - mean) * invstd * gamma + beta (+ res)); act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
+ * grad_y, y (unused for act 0), raw, the forward's batch mean / invstd [ld] in; grad_raw (may alias grad_y), grad_res (optional,
+ * the residual branch's gradient; may alias grad_y), grad_gamma / grad_beta [C] (optional) out. */
+size_t opp_batchnorm_backward_workspace_bytes(int rows, int ld);
+int opp_batchnorm_backward_nhwc(const float* grad_y, const float* y, const float* raw, int rows, int ld, int C, int act,
+                                const float* gamma, const float* mean, const float* invstd, float* grad_raw, float* grad_res,
+                                float* grad_gamma, float* grad_beta, void* workspace, size_t workspace_bytes, void* stream);
+/* Transpose of F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) (backbone/resnet.py:151,155):
+ * grad_in [B][Hr][Wr][ld] (+)= sum over the output pixels [B][2 Hr][2 Wr][ld] that read it. */
+int opp_upsample2x_backward_nhwc(const float* grad_out, int B, int Hr, int Wr, int ld, float* grad_in, int accumulate, void* stream);
+/* nn.LayerNorm (eps 1e-5) over rows of C = 64 / 128 / 256 values with the statistics kept for the backward
+ * (loftr_module/transformer.py:87-88, :92-94): y = (residual ? residual : 0) + LN(x) * gamma + beta; mean / rstd [rows] out.
+ * backward: grad_x [rows][C], grad_gamma / grad_beta [C] (fixed-order reduction over the rows). */
+int opp_layer_norm_train_forward(const float* x, const float* gamma, const float* beta, const float* residual, int rows, int C,
+                                 float* y, float* mean, float* rstd, void* stream);
+size_t opp_layer_norm_train_backward_workspace_bytes(int rows, int C);
+int opp_layer_norm_train_backward(const float* grad_y, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                  int rows, int C, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+/* Dual softmax of the score matrix sim [B][N][L] (utils/coarse_matching.py:115) with what opp_dual_softmax_backward needs:
+ * lse_row [B][N] = logsumexp over the cells, lse_col [B][L] = logsumexp over the points; conf (optional, may alias sim) =
+ * exp(sim - lse_col) * exp(sim - lse_row). */
+size_t opp_dual_softmax_forward_workspace_bytes(int B, int N, int L);
+int opp_dual_softmax_forward(const float* sim, int B, int N, int L, float* lse_row, float* lse_col, float* conf, void* workspace,
+                             size_t workspace_bytes, void* stream);
+/* FinePreprocess on a batch (loftr_module/fine_preprocess.py:41-55: F.unfold + [b_ids, j_ids] indexing): windows [M][W*W][C] from
+ * feat_f [B][Hf][Wf][C] around coarse cell j_ids[m] of image b_ids[m] (zeros outside the image); the backward adds the windows'
+ * gradients into grad_feat_f (zeroed first; overlapping windows are summed with fp32 atomics). */
+int opp_fine_window_gather(const float* feat_f, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids,
+                           int n_matches, int hc, int wc, int window, float* windows, void* stream);
+int opp_fine_window_gather_backward(const float* grad_windows, int B, int Hf, int Wf, int C, const long long* b_ids,
+                                    const long long* j_ids, int n_matches, int hc, int wc, int window, float* grad_feat_f,
+                                    void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

@@ -113,6 +113,29 @@ SIGNATURES = {
     "opp_pnp_ransac": (c_int, [c_void_p, c_void_p, c_int, POINTER(ctypes.c_double), ctypes.c_double, ctypes.c_double,
                                c_int, ctypes.c_uint, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_size_t, c_void_p]),
+    "opp_backbone_tape_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_backbone_train_tape_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_backbone_train_tape": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                        c_void_p, c_size_t, c_void_p]),
+    "opp_backbone_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_backbone_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p,
+                                      c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "opp_conv2d_backward_workspace_bytes": (c_size_t, [c_int] * 8),
+    "opp_conv2d_backward_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_size_t, c_void_p]),
+    "opp_batchnorm_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "opp_batchnorm_backward_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_upsample2x_backward_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "opp_layer_norm_train_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "opp_layer_norm_train_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "opp_layer_norm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_size_t, c_void_p]),
+    "opp_dual_softmax_forward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "opp_dual_softmax_forward": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_fine_window_gather": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "opp_fine_window_gather_backward": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                                c_void_p, c_void_p]),
     "opp_profile_start": (c_int, [c_int, c_int, c_int]),
     "opp_profile_stop": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int)]),
 }

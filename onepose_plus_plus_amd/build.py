@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_build")
 LIB = os.path.join(HERE, "libopp_hip.so")
-SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "stem_direct.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "bn_train.hip", "bankbuild.hip", "loss.hip", "linear_bwd.hip", "linattn_train.hip", "api.hip"]
+SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "stem_direct.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "bn_train.hip", "bankbuild.hip", "loss.hip", "linear_bwd.hip", "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

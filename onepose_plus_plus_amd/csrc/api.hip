@@ -801,6 +801,389 @@ extern "C" int opp_backbone_train(opp_ctx* ctx, const float* image, int B, int H
   return backbone_train_impl(ctx, image, B, H, W, feat_c, feat_f, bn_stats, a, (hipStream_t)stream);
 }
 
+// ----------------------------------------------------------------------------------------
+// training step: backbone forward that KEEPS what its backward needs (the "tape"), and that backward
+// (PL_OnePosePlus.training_step, lightning_model:54-81, differentiating ResNetFPN_8_2.forward, resnet.py:141-164)
+// ----------------------------------------------------------------------------------------
+namespace {
+
+struct TapeBlock { float *raw1, *t, *raw2, *rawd, *y; };
+struct Tape {
+  float *raw0, *x0;                 // stem: raw convolution output, relu(bn(.))
+  TapeBlock blk[6];                 // conv1 raw, relu(bn1), conv2 raw, downsample raw (or null), block output
+  float *l2, *raw_u2, *u2, *x2o, *l1, *raw_u1, *u1;
+  float* stats;                     // [n_bn][512]: batch mean [0, 256) and 1 / sqrt(var + eps) [256, 512) of BatchNorm slot i
+};
+
+size_t plan_tape(const opp_ctx* c, int B, int H, int W, Arena& a, Tape& t) {
+  const size_t p2 = (size_t)B * (H / 2) * (W / 2), p4 = (size_t)B * (H / 4) * (W / 4), p8 = (size_t)B * (H / 8) * (W / 8);
+  const int c1 = pad32(c->cfg.block_dims[0]), c2 = pad32(c->cfg.block_dims[1]), c3 = pad32(c->cfg.block_dims[2]);
+  t.raw0 = a.f(p2 * c1);
+  t.x0 = a.f(p2 * c1);
+  const size_t px[6] = {p2, p2, p4, p4, p8, p8};
+  const int ch[6] = {c1, c1, c2, c2, c3, c3};
+  for (int i = 0; i < 6; ++i) {
+    t.blk[i].raw1 = a.f(px[i] * ch[i]);
+    t.blk[i].t = a.f(px[i] * ch[i]);
+    t.blk[i].raw2 = a.f(px[i] * ch[i]);
+    t.blk[i].rawd = c->blocks[i].has_down ? a.f(px[i] * ch[i]) : nullptr;
+    t.blk[i].y = a.f(px[i] * ch[i]);
+  }
+  t.l2 = a.f(p4 * c3);
+  t.raw_u2 = a.f(p4 * c3);
+  t.u2 = a.f(p4 * c3);
+  t.x2o = a.f(p4 * c2);
+  t.l1 = a.f(p2 * c2);
+  t.raw_u1 = a.f(p2 * c2);
+  t.u1 = a.f(p2 * c2);
+  t.stats = a.f(c->bn_names.size() * 512);
+  return a.off;
+}
+
+size_t plan_tape_ws(const opp_ctx* c, int B, int H, int W, Arena& a, float** col, float** dsbuf, void** scratch) {
+  const size_t p2 = (size_t)B * (H / 2) * (W / 2), p4 = (size_t)B * (H / 4) * (W / 4);
+  *col = a.f(p2 * 64);
+  *dsbuf = a.f(p4 * pad32(c->cfg.block_dims[2] > c->cfg.block_dims[1] ? c->cfg.block_dims[2] : c->cfg.block_dims[1]));
+  *scratch = a.raw(opp_bn_train_scratch_bytes((int)p2, 256));
+  return a.off;
+}
+
+int backbone_tape_impl(opp_ctx* c, const float* image, int B, int H, int W, float* feat_c, float* feat_f, float* bn_stats, Tape& t,
+                       Arena& a, hipStream_t s) {
+  OPP_CHECK_ARG(c && c->packed && c->train_packed, "backbone_train_tape: training weights not packed (opp_pack_train_weights)");
+  OPP_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone_train_tape: bad B / H / W (%d, %dx%d)", B, H, W);
+  float *col, *dsbuf;
+  void* scratch;
+  plan_tape_ws(c, B, H, W, a, &col, &dsbuf, &scratch);
+  if (!a.ok) {
+    opp_set_error("backbone_train_tape: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  const int hp = gemm_prec(c->cfg);
+  const float eps = 1e-5f;
+  auto conv_bn = [&](const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int act, float* raw, float* y) -> int {
+    const int Ho = (Hin + 2 * (d.ks / 2) - d.ks) / stride + 1, Wo = (Win + 2 * (d.ks / 2) - d.ks) / stride + 1;
+    OPP_TRY(run_conv(x, Hin, Win, d, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, raw, s, hp, -1, B, true));
+    float* st = t.stats + (size_t)d.bn_slot * 512;
+    return opp_bn_train(raw, B * Ho * Wo, d.cout_pad(), d.cout, d.gamma, d.beta, eps, res, act, y,
+                        bn_stats ? bn_stats + (size_t)d.bn_slot * 512 : nullptr, scratch, s, st, st + 256);
+  };
+  auto block = [&](const float* x, int Hin, int Win, const BlockDesc& bd, int stride, TapeBlock& tb) -> int {
+    const int Ho = Hin / stride, Wo = Win / stride;
+    OPP_TRY(conv_bn(x, Hin, Win, bd.conv1, stride, nullptr, OPP_ACT_RELU, tb.raw1, tb.t));
+    const float* shortcut = x;
+    if (bd.has_down) {
+      OPP_TRY(conv_bn(x, Hin, Win, bd.down, stride, nullptr, OPP_ACT_NONE, tb.rawd, dsbuf));
+      shortcut = dsbuf;
+    }
+    return conv_bn(tb.t, Ho, Wo, bd.conv2, 1, shortcut, OPP_ACT_RELU, tb.raw2, tb.y);
+  };
+  OPP_TRY(opp_stem_im2col(image, B, H, W, col, s));
+  {
+    OppGemm g;
+    g.tile_policy = t_tile_policy;
+    g.A0 = col;
+    g.lda0 = 64;
+    g.ksplit = 64;
+    g.W = c->stem.w_train;
+    g.ldw = (int)split_floats(64, hp);
+    g.M = B * H2 * W2;
+    g.N = c->stem.cout;
+    g.K = 64;
+    g.C = t.raw0;
+    g.ldc = pad32(c->stem.cout);
+    g.n_store = pad32(c->stem.cout);
+    g.prec = hp;
+    OPP_TRY(opp_gemm_launch(g, s));
+    float* st = t.stats + (size_t)c->stem.bn_slot * 512;
+    OPP_TRY(opp_bn_train(t.raw0, B * H2 * W2, pad32(c->stem.cout), c->stem.cout, c->stem.gamma, c->stem.beta, eps, nullptr, OPP_ACT_RELU,
+                         t.x0, bn_stats ? bn_stats + (size_t)c->stem.bn_slot * 512 : nullptr, scratch, s, st, st + 256));
+  }
+  OPP_TRY(block(t.x0, H2, W2, c->blocks[0], 1, t.blk[0]));
+  OPP_TRY(block(t.blk[0].y, H2, W2, c->blocks[1], 1, t.blk[1]));
+  OPP_TRY(block(t.blk[1].y, H2, W2, c->blocks[2], 2, t.blk[2]));
+  OPP_TRY(block(t.blk[2].y, H4, W4, c->blocks[3], 1, t.blk[3]));
+  OPP_TRY(block(t.blk[3].y, H4, W4, c->blocks[4], 2, t.blk[4]));
+  OPP_TRY(block(t.blk[4].y, H8, W8, c->blocks[5], 1, t.blk[5]));
+  const float *x1 = t.blk[1].y, *x2 = t.blk[3].y, *x3 = t.blk[5].y;
+  OPP_TRY(run_conv(x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp, -1, B));
+  OPP_TRY(run_conv(x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, t.l2, s, hp, -1, B));
+  OPP_TRY(conv_bn(t.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_ACT_LEAKY, t.raw_u2, t.u2));
+  OPP_TRY(run_conv(t.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, t.x2o, s, hp, -1, B));
+  OPP_TRY(run_conv(x1, H2, W2, c->l1_out, 1, t.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, t.l1, s, hp, -1, B));
+  OPP_TRY(conv_bn(t.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_ACT_LEAKY, t.raw_u1, t.u1));
+  OPP_TRY(run_conv(t.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp, -1, B));
+  return OPP_OK;
+}
+
+// ---- backward of ONE convolution over NHWC tensors (channel counts padded to 32) --------------------------------------------
+struct ConvBwdWs {
+  float *wt_tmp = nullptr, *wt_pack = nullptr, *wt_split = nullptr;   // flipped / transposed weight, packed, pre-split
+  float* zbuf = nullptr;                                               // zero-inserted dY of a stride-2 convolution
+  void* geo = nullptr;
+  void* wg = nullptr;
+  size_t wg_bytes = 0;
+};
+struct ConvBwdNeed { size_t wt_tmp = 0, wt_pack = 0, wt_split = 0, zbuf = 0, geo = 0, wg = 0; };
+
+void conv_bwd_need(ConvBwdNeed& n, int B, int Hin, int Win, int cin, int cout, int ks, int stride, bool need_dx, bool need_dw, int prec) {
+  const int Ho = (Hin + 2 * (ks / 2) - ks) / stride + 1, Wo = (Win + 2 * (ks / 2) - ks) / stride + 1;
+  auto mx = [](size_t& a, size_t b) { a = b > a ? b : a; };
+  if (need_dx) {
+    mx(n.wt_tmp, (size_t)cout * cin * ks * ks);
+    const size_t pk = (size_t)pad32(cin) * opp_conv_k(cout, ks);
+    mx(n.wt_pack, pk);
+    mx(n.wt_split, split_floats(pk, prec));
+    if (stride == 2) mx(n.zbuf, (size_t)B * Hin * Win * pad32(cout));
+  }
+  if (need_dw) {
+    if (!(ks == 1 && stride == 1)) mx(n.geo, opp_conv_geo_entries(B * Ho * Wo) * 8);
+    mx(n.wg, opp_conv_wgrad_ws_bytes(B * Ho * Wo, pad32(cout), pad32(cin), ks));
+  }
+}
+void conv_bwd_alloc(Arena& a, const ConvBwdNeed& n, ConvBwdWs& w) {
+  w.wt_tmp = a.f(n.wt_tmp);
+  w.wt_pack = a.f(n.wt_pack);
+  w.wt_split = a.f(n.wt_split);
+  w.zbuf = a.f(n.zbuf);
+  w.geo = a.raw(n.geo);
+  w.wg = a.raw(n.wg);
+  w.wg_bytes = n.wg;
+}
+
+// x [B][Hin][Win][pad32(cin)], w [cout][cin][ks][ks] (PyTorch), dy [B][Ho][Wo][pad32(cout)] (padded channels zero).
+// dx (optional) [B][Hin][Win][pad32(cin)] = conv_transpose(dy, w) (+ dx_add, same shape, may alias dx); dw (optional) in PyTorch layout.
+int conv_backward(const float* x, int B, int Hin, int Win, int cin, const float* w, int cout, int ks, int stride, const float* dy, float* dx,
+                  const float* dx_add, float* dw, int prec, const ConvBwdWs& ws, hipStream_t s) {
+  OPP_CHECK_ARG(stride == 1 || (stride == 2 && Hin % 2 == 0 && Win % 2 == 0), "conv_backward: stride must be 1 or 2 (even input size)");
+  OPP_CHECK_ARG(prec == OPP_PREC_FP32 || prec == OPP_PREC_BF16X3, "conv_backward: arithmetic must be fp32 or bf16x3");
+  const int pad = ks / 2;
+  const int Ho = (Hin + 2 * pad - ks) / stride + 1, Wo = (Win + 2 * pad - ks) / stride + 1;
+  const int cin_pad = pad32(cin), cout_pad = pad32(cout);
+  if (dw) {
+    const void* geo = nullptr;
+    if (!(ks == 1 && stride == 1)) {
+      OPP_TRY(opp_conv_geo(B, Ho, Wo, Hin, Win, ks, stride, pad, ws.geo, s));
+      geo = ws.geo;
+    }
+    OPP_TRY(opp_conv_wgrad(dy, cout_pad, x, cin_pad, (size_t)B * Hin * Win, geo, B * Ho * Wo, Win, ks, cout, cin, dw, 0, ws.wg, ws.wg_bytes, s));
+  }
+  if (dx) {
+    // the input gradient is a stride-1 convolution of (zero-inserted) dy with the flipped, transposed weight
+    OPP_TRY(opp_conv_flip_transpose(w, cout, cin, ks, ws.wt_tmp, s));
+    OPP_TRY(opp_pack_conv(ws.wt_tmp, nullptr, cin, cout, ks, cin_pad, cout_pad, ws.wt_pack, s));
+    const size_t pk = (size_t)cin_pad * opp_conv_k(cout, ks);
+    const float* wp = ws.wt_pack;
+    if (prec == OPP_PREC_BF16X3) {
+      OPP_TRY(opp_b3_split(ws.wt_pack, ws.wt_split, pk, s));
+      wp = ws.wt_split;
+    }
+    const float* src = dy;
+    if (stride == 2) {
+      OPP_TRY(opp_conv_dilate2(dy, B, Ho, Wo, cout_pad, ws.zbuf, s));
+      src = ws.zbuf;
+    }
+    OppGemm g;
+    g.tile_policy = t_tile_policy;
+    g.conv = 1;
+    g.prec = prec;
+    g.A0 = src;
+    g.Bn = B;
+    g.Hin = Hin;
+    g.Win = Win;
+    g.Cin = cout_pad;
+    g.ksize = ks;
+    g.stride = 1;
+    g.pad = pad;
+    g.Hout = Hin;
+    g.Wout = Win;
+    g.W = wp;
+    g.K = opp_conv_k(cout, ks);
+    g.tail_grp = opp_conv_tail_grp(cout, ks);
+    g.ldw = (int)split_floats((size_t)g.K, prec);
+    g.M = B * Hin * Win;
+    g.N = cin_pad;
+    g.C = dx;
+    g.ldc = cin_pad;
+    g.n_store = cin_pad;
+    if (dx_add) {
+      g.res_mode = OPP_RES_DIRECT;
+      g.R = dx_add;
+      g.ldr = cin_pad;
+    }
+    g.alg_flops = 2.0 * (double)B * Ho * Wo * (double)cout * (double)(ks * ks * cin);
+    OPP_TRY(opp_gemm_launch(g, s));
+  }
+  return OPP_OK;
+}
+
+struct BwdBufs {
+  float *g2a, *g2b, *g2c, *g4a, *g4b, *g4c, *g8a, *g8b, *g8c, *col;
+  void* bn_scratch;
+  ConvBwdWs cw;
+};
+
+size_t plan_backbone_bwd(const opp_ctx* c, int B, int H, int W, Arena& a, BwdBufs& b) {
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  const size_t p2 = (size_t)B * H2 * W2, p4 = (size_t)B * H4 * W4, p8 = (size_t)B * H8 * W8;
+  const int d1 = c->cfg.block_dims[0], d2 = c->cfg.block_dims[1], d3 = c->cfg.block_dims[2];
+  const int c1 = pad32(d1), c2 = pad32(d2), c3 = pad32(d3);
+  const int c12 = c1 > c2 ? c1 : c2, c23 = c2 > c3 ? c2 : c3;
+  b.g2a = a.f(p2 * c12);
+  b.g2b = a.f(p2 * c12);
+  b.g2c = a.f(p2 * c1);
+  b.g4a = a.f(p4 * c23);
+  b.g4b = a.f(p4 * c23);
+  b.g4c = a.f(p4 * c2);
+  b.g8a = a.f(p8 * c3);
+  b.g8b = a.f(p8 * c3);
+  b.g8c = a.f(p8 * c3);
+  b.col = a.f(p2 * 64);
+  b.bn_scratch = a.raw(opp_bn_bwd_scratch_bytes((int)p2, 256));
+  const int prec = gemm_prec(c->cfg);
+  ConvBwdNeed n;
+  conv_bwd_need(n, B, H2, W2, 64, c->stem.cout, 1, 1, false, true, prec);                       // stem as a 1x1 over the im2col rows
+  const int hin[6] = {H2, H2, H2, H4, H4, H8}, win[6] = {W2, W2, W2, W4, W4, W8}, str[6] = {1, 1, 2, 1, 2, 1};
+  for (int i = 0; i < 6; ++i) {
+    const BlockDesc& bd = c->blocks[i];
+    conv_bwd_need(n, B, hin[i], win[i], bd.conv1.cin, bd.conv1.cout, 3, str[i], true, true, prec);
+    conv_bwd_need(n, B, hin[i] / str[i], win[i] / str[i], bd.conv2.cin, bd.conv2.cout, 3, 1, true, true, prec);
+    if (bd.has_down) conv_bwd_need(n, B, hin[i], win[i], bd.down.cin, bd.down.cout, 1, str[i], true, true, prec);
+  }
+  conv_bwd_need(n, B, H8, W8, d3, c->l3_out.cout, 1, 1, true, true, prec);
+  conv_bwd_need(n, B, H4, W4, d2, c->l2_out.cout, 1, 1, true, true, prec);
+  conv_bwd_need(n, B, H4, W4, c->l2_out2a.cin, c->l2_out2a.cout, 3, 1, true, true, prec);
+  conv_bwd_need(n, B, H4, W4, c->l2_out2b.cin, c->l2_out2b.cout, 3, 1, true, true, prec);
+  conv_bwd_need(n, B, H2, W2, d1, c->l1_out.cout, 1, 1, true, true, prec);
+  conv_bwd_need(n, B, H2, W2, c->l1_out2a.cin, c->l1_out2a.cout, 3, 1, true, true, prec);
+  conv_bwd_need(n, B, H2, W2, c->l1_out2b.cin, c->l1_out2b.cout, 3, 1, true, true, prec);
+  conv_bwd_alloc(a, n, b.cw);
+  return a.off;
+}
+
+int backbone_backward_impl(opp_ctx* c, const float* image, int B, int H, int W, const Tape& t, const float* const* w, const float* dfc,
+                           const float* dff, float* const* grads, Arena& a, hipStream_t s) {
+  BwdBufs b;
+  plan_backbone_bwd(c, B, H, W, a, b);
+  if (!a.ok) {
+    opp_set_error("backbone_backward: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
+  const int prec = gemm_prec(c->cfg);
+  const float *x1 = t.blk[1].y, *x2 = t.blk[3].y, *x3 = t.blk[5].y;
+  // gradient of one convolution: weight gradient into the caller's tensor, input gradient into dx (+ dx_add)
+  auto conv_b = [&](const ConvDesc& d, const float* x, int Hin, int Win, int stride, const float* dy, float* dx, const float* dx_add) -> int {
+    return conv_backward(x, B, Hin, Win, d.cin, w[d.w_idx], d.cout, d.ks, stride, dy, dx, dx_add, grads[d.w_idx], prec, b.cw, s);
+  };
+  // BatchNorm (+ activation) behind convolution d: dy -> draw (in place unless `draw` is given), dres = dz
+  auto bn_b = [&](const ConvDesc& d, int rows, int act, const float* dy, const float* y, const float* raw, float* draw, float* dres) -> int {
+    const float* st = t.stats + (size_t)d.bn_slot * 512;
+    return opp_bn_backward(dy, y, raw, rows, d.cout_pad(), d.cout, act, d.gamma, st, st + 256, draw, dres, grads[d.bn_idx], grads[d.bn_idx + 1], 0,
+                           b.bn_scratch, s);
+  };
+  // BasicBlock backward (resnet.py:37-45).  dy: gradient of the block output (overwritten); result: gradient of the block input in
+  // `out` (same buffer as dy for an identity shortcut; the finer-resolution buffer `out`, which may hold a gradient to add, otherwise)
+  auto block_b = [&](const BlockDesc& bd, const TapeBlock& tb, const float* x_in, int Hin, int Win, int stride, float* dy, float* tmp1, float* tmp2,
+                     float* out, bool out_has_add) -> int {
+    const int Ho = Hin / stride, Wo = Win / stride, rows = B * Ho * Wo;
+    OPP_TRY(bn_b(bd.conv2, rows, OPP_ACT_RELU, dy, tb.y, tb.raw2, tmp1, dy));                       // tmp1 = d raw2, dy = dz (shortcut gradient)
+    OPP_TRY(conv_b(bd.conv2, tb.t, Ho, Wo, 1, tmp1, tmp2, nullptr));                                  // tmp2 = d t
+    OPP_TRY(bn_b(bd.conv1, rows, OPP_ACT_RELU, tmp2, tb.t, tb.raw1, tmp2, nullptr));                  // tmp2 = d raw1
+    if (!bd.has_down) return conv_b(bd.conv1, x_in, Hin, Win, 1, tmp2, dy, dy);                       // d x = dgrad + dz, in place
+    OPP_TRY(bn_b(bd.down, rows, OPP_ACT_NONE, dy, nullptr, tb.rawd, dy, nullptr));                    // dy = d raw_down
+    OPP_TRY(conv_b(bd.down, x_in, Hin, Win, stride, dy, out, out_has_add ? out : nullptr));
+    return conv_b(bd.conv1, x_in, Hin, Win, stride, tmp2, out, out);
+  };
+  auto copy = [&](float* dst, const float* src, size_t n) -> int { return copy_f(dst, src, n, s); };
+
+  // FPN head (resnet.py:149-157), fine branch first
+  OPP_TRY(conv_b(c->l1_out2b, t.u1, H2, W2, 1, dff, b.g2a, nullptr));                                 // g2a = d u1
+  OPP_TRY(bn_b(c->l1_out2a, B * H2 * W2, OPP_ACT_LEAKY, b.g2a, t.u1, t.raw_u1, b.g2a, nullptr));
+  OPP_TRY(conv_b(c->l1_out2a, t.l1, H2, W2, 1, b.g2a, b.g2b, nullptr));                               // g2b = d l1
+  OPP_TRY(conv_b(c->l1_out, x1, H2, W2, 1, b.g2b, b.g2c, nullptr));                                   // g2c = d x1 (lateral part)
+  OPP_TRY(opp_upsample2x_backward(b.g2b, B, H4, W4, c->l1_out.cout_pad(), b.g4c, 0, s));              // g4c = d x2_out
+  OPP_TRY(conv_b(c->l2_out2b, t.u2, H4, W4, 1, b.g4c, b.g4b, nullptr));                               // g4b = d u2
+  OPP_TRY(bn_b(c->l2_out2a, B * H4 * W4, OPP_ACT_LEAKY, b.g4b, t.u2, t.raw_u2, b.g4b, nullptr));
+  OPP_TRY(conv_b(c->l2_out2a, t.l2, H4, W4, 1, b.g4b, b.g4a, nullptr));                               // g4a = d l2
+  OPP_TRY(conv_b(c->l2_out, x2, H4, W4, 1, b.g4a, b.g4c, nullptr));                                   // g4c = d x2 (lateral part)
+  OPP_TRY(copy(b.g8a, dfc, (size_t)B * H8 * W8 * c->l3_out.cout_pad()));
+  OPP_TRY(opp_upsample2x_backward(b.g4a, B, H8, W8, c->l3_out.cout_pad(), b.g8a, 1, s));              // g8a = d feat_c (both consumers)
+  OPP_TRY(conv_b(c->l3_out, x3, H8, W8, 1, b.g8a, b.g8b, nullptr));                                   // g8b = d x3
+  // residual stages, last to first
+  OPP_TRY(block_b(c->blocks[5], t.blk[5], t.blk[4].y, H8, W8, 1, b.g8b, b.g8a, b.g8c, b.g8b, false));
+  OPP_TRY(block_b(c->blocks[4], t.blk[4], x2, H4, W4, 2, b.g8b, b.g8a, b.g8c, b.g4c, true));          // g4c = d x2 (all consumers)
+  OPP_TRY(block_b(c->blocks[3], t.blk[3], t.blk[2].y, H4, W4, 1, b.g4c, b.g4a, b.g4b, b.g4c, false));
+  OPP_TRY(block_b(c->blocks[2], t.blk[2], x1, H2, W2, 2, b.g4c, b.g4a, b.g4b, b.g2c, true));          // g2c = d x1 (all consumers)
+  OPP_TRY(block_b(c->blocks[1], t.blk[1], t.blk[0].y, H2, W2, 1, b.g2c, b.g2a, b.g2b, b.g2c, false));
+  OPP_TRY(block_b(c->blocks[0], t.blk[0], t.x0, H2, W2, 1, b.g2c, b.g2a, b.g2b, b.g2c, false));
+  // stem (resnet.py:143): BatchNorm + ReLU backward, weight gradient over the im2col rows (k = ky * 7 + kx < 49)
+  OPP_TRY(bn_b(c->stem, B * H2 * W2, OPP_ACT_RELU, b.g2c, t.x0, t.raw0, b.g2c, nullptr));
+  OPP_TRY(opp_stem_im2col(image, B, H, W, b.col, s));
+  return opp_conv_wgrad(b.g2c, pad32(c->stem.cout), b.col, 64, (size_t)B * H2 * W2, nullptr, B * H2 * W2, W2, 1, c->stem.cout, 49,
+                        grads[c->stem.w_idx], 0, b.cw.wg, b.cw.wg_bytes, s);
+}
+
+}  // namespace
+
+extern "C" size_t opp_backbone_tape_bytes(const opp_ctx* ctx, int B, int H, int W) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  Tape t;
+  return opp_align(plan_tape(ctx, B, H, W, a, t)) + 256;
+}
+
+extern "C" size_t opp_backbone_train_tape_workspace_bytes(const opp_ctx* ctx, int B, int H, int W) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  float *col, *ds;
+  void* sc;
+  return opp_align(plan_tape_ws(ctx, B, H, W, a, &col, &ds, &sc)) + 256;
+}
+
+extern "C" int opp_backbone_train_tape(opp_ctx* ctx, const float* image, int B, int H, int W, float* feat_c, float* feat_f, float* bn_stats,
+                                       void* tape, size_t tape_bytes, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
+  OPP_CHECK_ARG(ctx && image && feat_c && feat_f && tape && ws, "backbone_train_tape: null argument");
+  OPP_CHECK_ARG(gemm_prec(ctx->cfg) != OPP_PREC_FP16X2, "backbone_train_tape: the training step runs in bf16x3 or fp32");
+  Arena ta(tape, tape_bytes);
+  Tape t;
+  plan_tape(ctx, B, H, W, ta, t);
+  OPP_CHECK_ARG(ta.ok, "backbone_train_tape: tape buffer too small (%zu bytes)", tape_bytes);
+  Arena a(ws, ws_bytes);
+  return backbone_tape_impl(ctx, image, B, H, W, feat_c, feat_f, bn_stats, t, a, (hipStream_t)stream);
+}
+
+extern "C" size_t opp_backbone_backward_workspace_bytes(const opp_ctx* ctx, int B, int H, int W) {
+  if (!ctx) return 0;
+  Arena a(nullptr, 0);
+  BwdBufs b;
+  return opp_align(plan_backbone_bwd(ctx, B, H, W, a, b)) + 256;
+}
+
+extern "C" int opp_backbone_backward(opp_ctx* ctx, const float* image, int B, int H, int W, const void* tape, size_t tape_bytes,
+                                     const float* const* weights, int n_weights, const float* grad_feat_c, const float* grad_feat_f,
+                                     float* const* grads, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
+  OPP_CHECK_ARG(ctx && image && tape && weights && grad_feat_c && grad_feat_f && grads && ws, "backbone_backward: null argument");
+  OPP_CHECK_ARG(ctx->train_packed, "backbone_backward: training weights not packed");
+  OPP_CHECK_ARG(n_weights == (int)ctx->table.size(), "backbone_backward: expected %d weight tensors, got %d", (int)ctx->table.size(), n_weights);
+  Arena ta(const_cast<void*>(tape), tape_bytes);
+  Tape t;
+  plan_tape(ctx, B, H, W, ta, t);
+  OPP_CHECK_ARG(ta.ok, "backbone_backward: tape buffer too small (%zu bytes)", tape_bytes);
+  std::vector<const ConvDesc*> cv;
+  cv.push_back(&ctx->stem);
+  for (ConvDesc* d : all_convs(ctx)) cv.push_back(d);
+  for (const ConvDesc* d : cv) {
+    OPP_CHECK_ARG(weights[d->w_idx] && grads[d->w_idx], "backbone_backward: weight / gradient pointer %d is null", d->w_idx);
+    if (d->bn_idx >= 0) OPP_CHECK_ARG(grads[d->bn_idx] && grads[d->bn_idx + 1], "backbone_backward: BatchNorm gradient pointer %d is null", d->bn_idx);
+  }
+  Arena a(ws, ws_bytes);
+  return backbone_backward_impl(ctx, image, B, H, W, t, weights, grad_feat_c, grad_feat_f, grads, a, (hipStream_t)stream);
+}
+
 extern "C" size_t opp_backbone_workspace_bytes(const opp_ctx* ctx, int H, int W) {
   if (!ctx) return 0;
   Arena a(nullptr, 0);
@@ -1504,4 +1887,71 @@ extern "C" int opp_linear_layernorm(const float* A, int M, int K, const float* W
 extern "C" int opp_layer_norm(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
                               int rows, int C, void* stream) {
   return opp_layernorm(x, C, gamma, beta, residual, C, out, C, rows, C, 1e-5f, (hipStream_t)stream);
+}
+
+// ---- training step: building blocks of the backward, exported for the autograd nodes and the stage-level tests -------------
+extern "C" size_t opp_conv2d_backward_workspace_bytes(int B, int Hin, int Win, int cin, int cout, int ks, int stride, int prec) {
+  ConvBwdNeed n;
+  conv_bwd_need(n, B, Hin, Win, cin, cout, ks, stride, true, true, prec);
+  Arena a(nullptr, 0);
+  ConvBwdWs w;
+  conv_bwd_alloc(a, n, w);
+  return opp_align(a.off) + 256;
+}
+
+extern "C" int opp_conv2d_backward_nhwc(const float* x, int B, int Hin, int Win, int cin, const float* w, int cout, int ks, int stride,
+                                        const float* grad_y, float* grad_x, float* grad_w, int prec, void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(x && w && grad_y && ws && (grad_x || grad_w), "conv2d_backward: null argument");
+  OPP_CHECK_ARG(ks == 1 || ks == 3, "conv2d_backward: kernel size must be 1 or 3");
+  ConvBwdNeed n;
+  conv_bwd_need(n, B, Hin, Win, cin, cout, ks, stride, grad_x != nullptr, grad_w != nullptr, prec);
+  Arena a(ws, ws_bytes);
+  ConvBwdWs cw;
+  conv_bwd_alloc(a, n, cw);
+  OPP_CHECK_ARG(a.ok, "conv2d_backward: workspace too small");
+  return conv_backward(x, B, Hin, Win, cin, w, cout, ks, stride, grad_y, grad_x, nullptr, grad_w, prec, cw, (hipStream_t)stream);
+}
+
+extern "C" size_t opp_batchnorm_backward_workspace_bytes(int rows, int ld) { return opp_bn_bwd_scratch_bytes(rows, ld) + 256; }
+
+extern "C" int opp_batchnorm_backward_nhwc(const float* grad_y, const float* y, const float* raw, int rows, int ld, int C, int act, const float* gamma,
+                                           const float* mean, const float* invstd, float* grad_raw, float* grad_res, float* grad_gamma,
+                                           float* grad_beta, void* ws, size_t ws_bytes, void* stream) {
+  OPP_CHECK_ARG(ws && ws_bytes >= opp_bn_bwd_scratch_bytes(rows, ld), "batchnorm_backward: workspace too small");
+  return opp_bn_backward(grad_y, y, raw, rows, ld, C, act, gamma, mean, invstd, grad_raw, grad_res, grad_gamma, grad_beta, 0, ws, (hipStream_t)stream);
+}
+
+extern "C" int opp_upsample2x_backward_nhwc(const float* grad_out, int B, int Hr, int Wr, int ld, float* grad_in, int accumulate, void* stream) {
+  return opp_upsample2x_backward(grad_out, B, Hr, Wr, ld, grad_in, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int opp_layer_norm_train_forward(const float* x, const float* gamma, const float* beta, const float* residual, int rows, int C, float* y,
+                                            float* mean, float* rstd, void* stream) {
+  return opp_ln_forward(x, gamma, beta, residual, rows, C, 1e-5f, y, mean, rstd, (hipStream_t)stream);
+}
+
+extern "C" size_t opp_layer_norm_train_backward_workspace_bytes(int rows, int C) { return opp_ln_backward_ws_bytes(rows, C) + 256; }
+
+extern "C" int opp_layer_norm_train_backward(const float* grad_y, const float* x, const float* gamma, const float* mean, const float* rstd, int rows,
+                                             int C, float* grad_x, float* grad_gamma, float* grad_beta, void* ws, size_t ws_bytes, void* stream) {
+  return opp_ln_backward(grad_y, x, gamma, mean, rstd, rows, C, grad_x, grad_gamma, grad_beta, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t opp_dual_softmax_forward_workspace_bytes(int B, int N, int L) { return opp_lse_ws_bytes(B, N, L) + 256; }
+
+extern "C" int opp_dual_softmax_forward(const float* sim, int B, int N, int L, float* lse_row, float* lse_col, float* conf, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  return opp_dual_softmax_lse(sim, B, N, L, lse_row, lse_col, conf, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int opp_fine_window_gather(const float* feat_f, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids, int n_matches,
+                                      int hc, int wc, int window, float* windows, void* stream) {
+  OPP_CHECK_ARG(hc > 0 && Hf % hc == 0 && B > 0, "fine_window_gather: fine map height %d not a multiple of coarse %d", Hf, hc);
+  return opp_fine_gather_batch(feat_f, Hf, Wf, C, b_ids, j_ids, n_matches, wc, Hf / hc, window, windows, (hipStream_t)stream);
+}
+
+extern "C" int opp_fine_window_gather_backward(const float* grad_windows, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids,
+                                               int n_matches, int hc, int wc, int window, float* grad_feat_f, void* stream) {
+  OPP_CHECK_ARG(hc > 0 && Hf % hc == 0 && B > 0, "fine_window_gather_backward: fine map height %d not a multiple of coarse %d", Hf, hc);
+  return opp_fine_scatter_batch(grad_windows, B, Hf, Wf, C, b_ids, j_ids, n_matches, wc, Hf / hc, window, grad_feat_f, (hipStream_t)stream);
 }

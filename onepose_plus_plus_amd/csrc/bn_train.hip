@@ -120,12 +120,16 @@ size_t opp_bn_train_scratch_bytes(int rows, int ld) {
 }
 
 int opp_bn_train(const float* y, int rows, int ld, int C, const float* gamma, const float* beta, float eps, const float* res,
-                 int act, float* out, float* stat_out, void* scratch, hipStream_t stream) {
+                 int act, float* out, float* stat_out, void* scratch, hipStream_t stream, float* save_mean, float* save_invstd) {
   OPP_CHECK_ARG(y && gamma && beta && out && scratch && rows > 0 && ld % 4 == 0 && ld <= 256 && C <= ld, "bn_train: bad argument");
   const int blocks = opp_cdiv(rows, kBnRowsPerBlock);
   double* part = static_cast<double*>(scratch);
   float* mean = reinterpret_cast<float*>(static_cast<char*>(scratch) + opp_align((size_t)blocks * 2 * ld * sizeof(double)));
   float* invstd = reinterpret_cast<float*>(reinterpret_cast<char*>(mean) + opp_align((size_t)ld * sizeof(float)));
+  if (save_mean && save_invstd) {   // the training step's tape keeps the batch statistics [ld] for the backward (conv_bwd.hip)
+    mean = save_mean;
+    invstd = save_invstd;
+  }
   hipLaunchKernelGGL(bn_partial_kernel, dim3(blocks), dim3(64, 4), 0, stream, y, rows, ld, part);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(opp_cdiv(ld, 16)), dim3(256), 0, stream, part, blocks, rows, ld, C, eps, mean, invstd, stat_out);
   const size_t total = (size_t)rows * (ld / 4);

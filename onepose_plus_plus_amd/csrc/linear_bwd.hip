@@ -70,10 +70,16 @@ Plan make_plan(int M, int N, int K, int prec) {
   };
   p.off_wt = take((size_t)K * N);
   p.off_wts = take((size_t)K * N * sf / 2);
-  p.off_dyt = take((size_t)N * p.Mp);
-  p.off_xt = take((size_t)K * p.Mp);
-  p.off_xts = take((size_t)K * p.Mp * sf / 2);
-  p.off_part = take((size_t)p.splits * N * K);
+  if (prec == OPP_PREC_BF16X3) {
+    // weight gradient straight from the token-major operands (conv_bwd.hip: register-transposing loader, no transposed / split copies)
+    p.off_dyt = p.off_xt = p.off_xts = o;
+    p.off_part = take(opp_conv_wgrad_ws_bytes(M, N, K, 1) / sizeof(float));
+  } else {
+    p.off_dyt = take((size_t)N * p.Mp);
+    p.off_xt = take((size_t)K * p.Mp);
+    p.off_xts = take((size_t)K * p.Mp * sf / 2);
+    p.off_part = take((size_t)p.splits * N * K);
+  }
   p.total = o;
   return p;
 }
@@ -115,7 +121,9 @@ int opp_linear_bwd(const float* dY, const float* X, const float* W, int M, int N
     g.n_store = K;
     OPP_TRY(opp_gemm_launch(g, stream));
   }
-  if (dW) {   // dW = dY^T X : reduction over the tokens, split-K
+  if (dW && b3) {   // dW = dY^T X on the pixel-major weight-gradient kernel: a 1 x 1 "convolution" over M tokens
+    OPP_TRY(opp_conv_wgrad(dY, N, X, K, (size_t)M, nullptr, M, 0, 1, N, K, dW, accumulate_dw, base + p.off_part, opp_conv_wgrad_ws_bytes(M, N, K, 1), stream));
+  } else if (dW) {   // dW = dY^T X : reduction over the tokens, split-K
     float* dyt = base + p.off_dyt;
     float* xt = base + p.off_xt;
     float* xts = base + p.off_xts;

@@ -19,6 +19,7 @@ enum {
   OPP_PROF_ENC_CHAIN = 1009,       // enc_chain_kernel: one encoder layer behind the QKV projection (work = FLOPs, MFMA-bound)
   OPP_PROF_SCORE_SWEEP1 = 1010,    // gemm_ss_kernel<STATS>: score tiles -> dual-softmax statistics only (work = FLOPs)
   OPP_PROF_SCORE_SWEEP2 = 1011,
+  OPP_PROF_CONV_WGRAD = 1013,      // conv_wgrad_kernel: weight gradient of a convolution / Linear (work = FLOPs)
   OPP_PROF_SCORE_SS = 1012,        // gemm_ss_kernel<STATS_STORE>: score GEMM on pre-split operands, statistics + score matrix written (FLOPs)    // gemm_ss_kernel<CONF>: score tiles recomputed -> confidence matrix written once (work = FLOPs)
 };
 inline int opp_prof_gemm_symbol(int tile_cfg, int kind) { return kind * 256 + tile_cfg; }
@@ -168,7 +169,33 @@ int opp_transpose(const float* in, float* out, int batch, int R, int Cc, hipStre
 // out = act((y - mean_batch) * invstd_batch * gamma + beta (+ res)); stat_out [2][C] = batch mean, unbiased variance
 size_t opp_bn_train_scratch_bytes(int rows, int ld);
 int opp_bn_train(const float* y, int rows, int ld, int C, const float* gamma, const float* beta, float eps, const float* res,
-                 int act, float* out, float* stat_out, void* scratch, hipStream_t stream);
+                 int act, float* out, float* stat_out, void* scratch, hipStream_t stream, float* save_mean = nullptr, float* save_invstd = nullptr);
+// conv_bwd.hip -- backward of the backbone convolutions / BatchNorm / bilinear upsample for the training step
+size_t opp_conv_geo_entries(int P);     // int2 entries of the geometry table of P output pixels
+int opp_conv_geo(int B, int Ho, int Wo, int Hin, int Win, int ks, int stride, int pad, void* geo, hipStream_t stream);
+size_t opp_conv_wgrad_ws_bytes(int P, int cout_pad, int cin_pad, int ks);
+// dW [cout][cin][ks][ks] (+)= sum_p dY[p][co] X[geo(p) + tap][ci]; geo = null: X row p itself (ks = 1: a Linear's weight gradient)
+int opp_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, size_t x_pixels, const void* geo, int P, int Win, int ks, int cout, int cin,
+                   float* dW, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+int opp_conv_flip_transpose(const float* w, int cout, int cin, int ks, float* out, hipStream_t stream);
+int opp_conv_dilate2(const float* dy, int B, int Ho, int Wo, int ld, float* z, hipStream_t stream);
+size_t opp_bn_bwd_scratch_bytes(int rows, int ld);
+int opp_bn_backward(const float* dy, const float* y, const float* raw, int rows, int ld, int C, int act, const float* gamma, const float* mean,
+                    const float* invstd, float* draw, float* dres, float* dgamma, float* dbeta, int accumulate, void* scratch, hipStream_t stream);
+int opp_upsample2x_backward(const float* g, int B, int Hr, int Wr, int ld, float* dr, int accumulate, hipStream_t stream);
+// train_misc.hip -- LayerNorm with saved statistics + backward, log-sum-exps of the score matrix, fine windows of a batch
+int opp_ln_forward(const float* x, const float* gamma, const float* beta, const float* res, int rows, int C, float eps, float* y, float* mean,
+                   float* rstd, hipStream_t stream);
+size_t opp_ln_backward_ws_bytes(int rows, int C);
+int opp_ln_backward(const float* g, const float* x, const float* gamma, const float* mean, const float* rstd, int rows, int C, float* dx,
+                    float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t opp_lse_ws_bytes(int B, int N, int L);
+int opp_dual_softmax_lse(const float* S, int B, int N, int L, float* lse_row, float* lse_col, float* conf, void* ws, size_t ws_bytes,
+                         hipStream_t stream);
+int opp_fine_gather_batch(const float* feat, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids, int M, int wc, int stride, int Wwin,
+                          float* win, hipStream_t stream);
+int opp_fine_scatter_batch(const float* gwin, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids, int M, int wc, int stride,
+                           int Wwin, float* dfeat, hipStream_t stream);
 // kpt.hip
 int opp_kpt_stats(const float* kpts, int n, float* stats, hipStream_t stream);
 int opp_kpt_encode(const float* kpts, const float* stats, const float* bank, int n, const float* const* wt,
