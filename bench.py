@@ -572,9 +572,10 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
 def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
     """One training step at the per-GPU shape of BASELINE configs[4] (B = 4, 512x512, N = 7000 points padded as the
     reference's dataset does, train.yaml:185,194): train()-mode forward on the HIP path (BatchNorm batch statistics,
-    training branch of get_coarse_match, fine level on the padded matches), `fine_supervision` + `Loss` of this package
-    (focal loss over the 115 M-entry confidence matrix and its gradient in HIP), model backward (PyTorch ops
-    re-evaluating the graph, onepose_plus_plus_amd/train_autograd.py) and an AdamW update."""
+    training branch of get_coarse_match, fine level on the padded matches) built ONCE as a graph of autograd nodes whose
+    forward and backward are HIP kernels (onepose_plus_plus_amd/train_autograd.py: backbone with a tape, Linear, linear
+    attention, LayerNorm, coarse matcher, fine windows), `fine_supervision` + `Loss` of this package (focal loss over the
+    115 M-entry confidence matrix and its gradient in HIP), backward through those nodes and an AdamW update."""
     from onepose_plus_plus_amd import OnePosePlus_model, default_config
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
     B, N, hw = 4, 7000, (512, 512)
@@ -646,6 +647,7 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
             torch.cuda.synchronize(dev)
     loss_only()
     focal_ms = min(loss_only() for _ in range(3))
+    bwd = backward_kernel_split(torch, dev, model, base, hparams, loss_mod, fine_supervision)
     n_conf = B * N * 4096
     return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, 7000 points, train() mode, single stream; "
                         "step = model(batch), fine_supervision, Loss (focal + l2_with_std, train.yaml:129-144), backward, AdamW",
@@ -653,8 +655,49 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
             "step_ms": round(step_ms, 1), "step_samples_per_s": round(B / step_ms * 1e3, 2), "loss": round(loss, 5),
             "focal_loss_fwd_bwd_ms": round(focal_ms, 3),
             "focal_loss_alg_gbs": round(n_conf * 16.0 / (focal_ms * 1e-3) / 1e9, 1),
-            "note": "forward, focal loss and its gradient = hand-written HIP; model backward = PyTorch ops on the device "
-                    "(not hand-written yet)"}
+            "backward_ms_in_opp_kernels": bwd.get("hand_written_ms"), "backward_kernel_split": bwd,
+            "note": "forward and backward = one graph of HIP nodes (backbone conv dgrad / wgrad + BatchNorm backward, Linear, linear "
+                    "attention, LayerNorm, dual softmax, focal loss); PyTorch = autograd tape, elementwise glue, AdamW"}
+
+
+def backward_kernel_split(torch, dev, model, base, hparams, loss_mod, fine_supervision):
+    """Device time of ONE backward pass (loss.backward() of the training step) by who wrote the kernel, from torch.profiler's
+    kernel records: hand-written HIP of libopp_hip.so vs PyTorch's own elementwise / reduction kernels (at::native) vs vendor
+    libraries (MIOpen / rocBLAS / Tensile -- expected: none)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        d = dict(base)
+        model(d)
+        fine_supervision(d, hparams)
+        loss_mod(d)
+        for p in model.parameters():
+            p.grad = None
+        torch.cuda.synchronize(dev)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            d["loss"].backward()
+            torch.cuda.synchronize(dev)
+        ours = aten = vendor = 0.0
+        vendor_names = []
+        for e in prof.key_averages():
+            t = getattr(e, "self_device_time_total", None)
+            if t is None:
+                t = getattr(e, "self_cuda_time_total", 0.0)
+            if not t:
+                continue
+            name = e.key
+            low = name.lower()
+            if "miopen" in low or "igemm" in low or "cijk_" in low or "rocblas" in low or "tensile" in low:
+                vendor += t
+                vendor_names.append(name[:60])
+            elif "at::native" in name or "at::cuda" in name or "memcpy" in low or "memset" in low or "fill" in low:
+                aten += t
+            else:
+                ours += t
+        tot = ours + aten + vendor
+        return {"hand_written_ms": round(ours / 1e3, 2), "aten_elementwise_ms": round(aten / 1e3, 2), "vendor_library_ms": round(vendor / 1e3, 2),
+                "hand_written_frac": round(ours / tot, 3) if tot else None, "vendor_kernels": vendor_names[:6]}
+    except Exception as e:                    # the split is a report, never a reason to lose the leg
+        return {"error": str(e)[:200]}
 
 
 def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):

@@ -472,21 +472,19 @@ class OnePosePlus_model(nn.Module):
             raise RuntimeError("query_image must be a CUDA/ROCm tensor: the HIP path has no CPU fallback")
         if img.dim() != 4 or img.size(1) != 1 or img.size(0) < 1:
             raise NotImplementedError("HIP path supports query_image of shape [B,1,H,W] (got %s)" % (tuple(img.shape),))
+        # (the reference returns None and reports through `data`; returning the same dict as well costs nothing and lets wrappers
+        # that copy their inputs -- DistributedDataParallel rebuilds every dict it is given -- hand the results back: `out = ddp(d)`)
         if self.training:
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                # training step (lightning_model:54-81): forward on the HIP path; `conf_matrix` / `expec_f` carry a
-                # grad_fn whose backward re-evaluates the graph with PyTorch ops (train_autograd.TrainForward)
-                from .train_autograd import TrainForward
-                names, params = zip(*self.named_parameters())
-                conf, expec = TrainForward.apply(self, data, names, *params)
-                data["conf_matrix"] = conf
-                if self.config["fine_matching"]["enable"] and "expec_f" in data:
-                    data["expec_f"] = expec
-                return
-            return self._forward_train(data)
+            # training step (lightning_model:54-81): with gradients enabled the forward is built out of autograd nodes whose forward
+            # and backward are HIP kernels (train_autograd.py); `conf_matrix` / `expec_f` then carry a grad_fn
+            graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            self._forward_train(data, graph=graph)
+            return data
         if img.size(0) > 1 or "query_image_mask" in data:
-            return self._forward_batch(data)
-        return self._forward_single(data)
+            self._forward_batch(data)
+            return data
+        self._forward_single(data)
+        return data
 
     def _forward_batch(self, data):
         """B >= 1 with optional `query_image_mask`: every sample runs the B = 1 path with its own mask
@@ -545,7 +543,18 @@ class OnePosePlus_model(nn.Module):
     train_randint = staticmethod(torch.randint)
     bn_momentum = 0.1            # torch.nn.BatchNorm2d default, used by every BatchNorm of resnet.py
 
-    def _forward_train(self, data):
+    def _update_running_stats(self, lib, ctx, stats):
+        """running statistics after a train()-mode forward, like torch.nn.BatchNorm2d: stats [n_bn, 512] = batch mean | unbiased variance"""
+        with torch.no_grad():
+            m = self.bn_momentum
+            for i in range(lib.opp_num_bn_layers(ctx)):
+                name = lib.opp_bn_layer_name(ctx, i).decode()
+                C = lib.opp_bn_layer_channels(ctx, i)
+                self.get_buffer(name + ".running_mean").mul_(1 - m).add_(stats[i, :C], alpha=m)
+                self.get_buffer(name + ".running_var").mul_(1 - m).add_(stats[i, C:2 * C], alpha=m)
+                self.get_buffer(name + ".num_batches_tracked").add_(1)
+
+    def _forward_train(self, data, graph=False):
         """train()-mode forward (PL_OnePosePlus.training_step, lightning_model:54-81 -> OnePosePlusModel.py:96-201):
         ResNet-FPN with BatchNorm BATCH statistics over the whole batch (+ running-statistics update), per-sample
         coarse level, the training branch of get_coarse_match (coarse_matching.py:177-217: sub-sample the predicted
@@ -566,14 +575,17 @@ class OnePosePlus_model(nn.Module):
             raise RuntimeError("train() mode runs in 'bf16x3' or 'fp32'; gemm_precision %r is inference-only" % (self.gemm_precision,))
         try:
             with torch.cuda.device(device):
-                self._forward_train_impl(data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF)
+                self._forward_train_impl(data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF, graph)
         finally:
             # parameters and running statistics move between training steps: on EVERY exit path the eval packing
             # (folded BatchNorm) and the cached 3D-point tokens (keypoint-MLP weights) of this module are stale
             self._rt["dirty"] = True
             self._rt["obj"] = None
 
-    def _forward_train_impl(self, data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF):
+    def _forward_train_impl(self, data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF, graph=False):
+        """graph = True: gradients are wanted -- the same stages as autograd nodes (train_autograd.py), built once, no re-evaluation"""
+        if graph:
+            from . import train_autograd as TA
         self._rt["dirty"] = True                      # parameters change between training steps: always repack
         self._rt["obj"] = None
         lib, ctx = self._ensure_ready(device)
@@ -600,7 +612,9 @@ class OnePosePlus_model(nn.Module):
         feat_c = torch.empty((B, L, dC), dtype=torch.float32, device=device)
         feat_f = torch.empty((B, hf * wf, dF), dtype=torch.float32, device=device)
         frozen = bool(self.loftr_backbone_pretrained) and bool(cfg["loftr_backbone"]["pretrained_fix"])
-        if frozen:
+        if graph and not frozen:
+            feat_c, feat_f = TA.backbone_node(self, lib, ctx, img_c)
+        elif frozen:
             nb = lib.opp_backbone_workspace_bytes(ctx, H, W)
             ws = self._workspace(nb, device)
             for b in range(B):
@@ -614,29 +628,27 @@ class OnePosePlus_model(nn.Module):
             ws = self._workspace(nb, device)
             _lib.check(lib.opp_backbone_train(ctx, img_c.data_ptr(), B, H, W, feat_c.data_ptr(), feat_f.data_ptr(),
                                               stats.data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_backbone_train")
-            with torch.no_grad():                  # running statistics, like torch.nn.BatchNorm2d in train()
-                m = self.bn_momentum
-                for i in range(n_bn):
-                    name = lib.opp_bn_layer_name(ctx, i).decode()
-                    C = lib.opp_bn_layer_channels(ctx, i)
-                    self.get_buffer(name + ".running_mean").mul_(1 - m).add_(stats[i, :C], alpha=m)
-                    self.get_buffer(name + ".running_var").mul_(1 - m).add_(stats[i, C:2 * C], alpha=m)
-                    self.get_buffer(name + ".num_batches_tracked").add_(1)
+            self._update_running_stats(lib, ctx, stats)
 
         # 2./3. coarse level per sample (:131-167)
-        conf = torch.empty((B, N, L), dtype=torch.float32, device=device)
-        i_all = torch.empty((B, N), dtype=torch.int64, device=device)
-        j_all = torch.empty((B, N), dtype=torch.int64, device=device)
-        c_all = torch.empty((B, N), dtype=torch.float32, device=device)
-        mkc = torch.empty((N, 2), dtype=torch.float32, device=device)
-        mk3 = torch.empty((N, 3), dtype=torch.float32, device=device)
-        counts = torch.zeros((B, 2), dtype=torch.int32, device=device)
-        tokens = torch.empty((L + N, dC), dtype=torch.float32, device=device)
-        wsb = max(lib.opp_transformer_workspace_bytes(ctx, 0, 1, L, N), lib.opp_coarse_match_workspace_bytes(ctx, N, L), 4096)
-        ws = self._workspace(wsb, device)
         scale_c = float(H) / float(hc)
+        if graph:
+            params = dict(self.named_parameters())
+            conf, aux = TA.coarse_level_graph(self, lib, ctx, params, feat_c, pe, kpts, bank_c, mask, qscale, hc, wc, scale_c)
+            i_all, j_all, c_all, counts = aux["i_all"], aux["j_all"], aux["c_all"], aux["counts"]
+        else:
+            conf = torch.empty((B, N, L), dtype=torch.float32, device=device)
+            i_all = torch.empty((B, N), dtype=torch.int64, device=device)
+            j_all = torch.empty((B, N), dtype=torch.int64, device=device)
+            c_all = torch.empty((B, N), dtype=torch.float32, device=device)
+            mkc = torch.empty((N, 2), dtype=torch.float32, device=device)
+            mk3 = torch.empty((N, 3), dtype=torch.float32, device=device)
+            counts = torch.zeros((B, 2), dtype=torch.int32, device=device)
+            tokens = torch.empty((L + N, dC), dtype=torch.float32, device=device)
+            wsb = max(lib.opp_transformer_workspace_bytes(ctx, 0, 1, L, N), lib.opp_coarse_match_workspace_bytes(ctx, N, L), 4096)
+            ws = self._workspace(wsb, device)
         try:
-            for b in range(B):
+            for b in range(B if not graph else 0):
                 _lib.check(lib.opp_set_keypoint_extent_ref(ctx, kpts[0].data_ptr() if b > 0 else None, N if b > 0 else 0), "extent_ref")
                 _lib.check(lib.opp_set_query_mask(ctx, mask[b].data_ptr() if mask is not None else None), "query_mask")
                 _lib.check(lib.opp_coarse_tokens(ctx, feat_c[b].data_ptr(), pe.data_ptr() if pe is not None else None, L,
@@ -688,10 +700,18 @@ class OnePosePlus_model(nn.Module):
         data["W"] = cfg["loftr_fine"]["window_size"]
         Mp = int(b_ids.numel())
         assert Mp > 0, "M is always >0, when training, see coarse_matching.py"          # fine_matching.py:47
+        scale_f = float(H) / float(hf)
+        if graph:
+            expec = TA.fine_level_graph(self, params, feat_f, bank_f, b_ids, i_ids, j_ids, B, hf, wf, hc, wc)
+            with torch.no_grad():                                                         # build_mkpts, fine_matching.py:96-110
+                qs = scale_f * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_f
+                n_keep = int(keep.sum().item())
+                mk_f = mk_query[keep] + (expec[:, :2].detach() * (data["W"] // 2) * qs)[:n_keep]
+            data.update({"expec_f": expec, "mkpts_query_f": mk_f})
+            return
         expec = torch.empty((Mp, 3), dtype=torch.float32, device=device)
         mk_f = torch.empty((Mp, 2), dtype=torch.float32, device=device)
         mk_query_f32 = mk_query.to(torch.float32).contiguous()
-        scale_f = float(H) / float(hf)
         for b in range(B):
             sel = torch.nonzero(b_ids == b).flatten()
             mb = int(sel.numel())

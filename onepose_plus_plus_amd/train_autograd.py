@@ -23,9 +23,8 @@ import torch.nn.functional as F
 
 _EPS_BN = 1e-5
 _EPS_LN = 1e-5
-# arithmetic of the HipLinear nodes of the graph being re-evaluated (set by TrainForward.backward from the module's
-# gemm_precision: 2 = bf16x3, 0 = fp32); None = plain F.linear (CPU tensors, OPP_TRAIN_HIP_LINEAR=0)
-_HIP_LINEAR_PREC = None
+# `hp` below = arithmetic of the HIP nodes of the graph being built (2 = bf16x3, 0 = fp32, from the module's gemm_precision);
+# None = plain torch ops (CPU tensors).  It is passed explicitly: a process-global would be shared by concurrent steps.
 
 
 class HipLinear(torch.autograd.Function):
@@ -126,11 +125,60 @@ class HipLinearAttention(torch.autograd.Function):
         return gq, gk, gv, None, None
 
 
-def _linear(x, w):
-    """F.linear(x, w) of a transformer Linear; on the device with the HIP backward unless switched off"""
-    if _HIP_LINEAR_PREC is not None and x.is_cuda and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0:
-        return HipLinear.apply(x, w, _HIP_LINEAR_PREC)
+class HipLayerNorm(torch.autograd.Function):
+    """nn.LayerNorm(C) (loftr_module/transformer.py:87-88, :92-94; eps 1e-5) over the last axis, C in (64, 128, 256), forward and
+    backward in libopp_hip.so (csrc/train_misc.hip: one wave per row; d gamma / d beta as a fixed-order reduction over the rows)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        from . import _lib
+        lib = _lib.load()
+        dev = x.device
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).to(torch.float32).contiguous()
+        g, b = gamma.to(torch.float32).contiguous(), beta.to(torch.float32).contiguous()
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=dev)
+        rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_layer_norm_train_forward(x2.data_ptr(), g.data_ptr(), b.data_ptr(), None, rows, C, y.data_ptr(), mean.data_ptr(),
+                                                        rstd.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "opp_layer_norm_train_forward")
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.lead = tuple(x.shape[:-1])
+        return y.view(*x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _lib
+        lib = _lib.load()
+        x2, g, mean, rstd = ctx.saved_tensors
+        dev = x2.device
+        rows, C = x2.shape
+        g2 = gy.reshape(rows, C).to(torch.float32).contiguous()
+        dx = torch.empty_like(x2)
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        nb = lib.opp_layer_norm_train_backward_workspace_bytes(rows, C)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_layer_norm_train_backward(g2.data_ptr(), x2.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C,
+                                                         dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), nb,
+                                                         torch.cuda.current_stream(dev).cuda_stream), "opp_layer_norm_train_backward")
+        return dx.view(*ctx.lead, C), dg, db
+
+
+def _linear(x, w, hp=None):
+    """F.linear(x, w) of a bias-free Linear; on the device a HIP node (forward, input and weight gradient on the MFMA GEMM)"""
+    if hp is not None and x.is_cuda and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0:
+        return HipLinear.apply(x, w, hp)
     return F.linear(x, w)
+
+
+def _layer_norm(x, w, b, hp=None):
+    if hp is not None and x.is_cuda and x.shape[-1] in (64, 128, 256):
+        return HipLayerNorm.apply(x, w, b)
+    return F.layer_norm(x, (x.shape[-1],), w, b, _EPS_LN)
 
 
 def _bn(p, name, x):
@@ -166,7 +214,7 @@ def _backbone(p, img, bn_eval_stats=None):
     return x3_out, F.conv2d(t, p[b + "layer1_outconv2.3.weight"], None, 1, 1)
 
 
-def _kpt_encoding(p, kpts, desc):
+def _kpt_encoding(p, kpts, desc, hp=None):
     """normalize_3d_keypoints + KeypointEncoding_linear (utils/normalize.py:16-26, utils/position_encoding.py:54-79;
     per-point channel norm = quirk q3, batch-0 extent = quirk q4)."""
     extent = kpts[0].max(dim=0).values - kpts[0].min(dim=0).values
@@ -174,7 +222,13 @@ def _kpt_encoding(p, kpts, desc):
     pre = "kpt_3d_pos_encoding.encoder."
     idxs = sorted({int(k[len(pre):].split(".")[0]) for k in p if k.startswith(pre)})
     for n, i in enumerate(idxs):
-        x = F.linear(x, p[pre + "%d.weight" % i], p[pre + "%d.bias" % i])
+        w, bias = p[pre + "%d.weight" % i], p[pre + "%d.bias" % i]
+        if hp is not None and x.is_cuda and w.shape[0] % 32 == 0:
+            # the 1x1 Conv1d layers as HIP Linear nodes; the 3-channel input of the first one zero-padded to the GEMM's K granule
+            kpad = (-w.shape[1]) % 32
+            x = _linear(F.pad(x, (0, kpad)) if kpad else x, F.pad(w, (0, kpad)) if kpad else w, hp) + bias
+        else:
+            x = F.linear(x, w, bias)
         if n < len(idxs) - 1:
             mu = x.mean(dim=-1, keepdim=True)
             var = x.var(dim=-1, unbiased=False, keepdim=True)
@@ -182,8 +236,8 @@ def _kpt_encoding(p, kpts, desc):
     return desc + x.transpose(2, 1)
 
 
-def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loftr_module/linear_attention.py:29-61
-    if _HIP_LINEAR_PREC is not None and q.is_cuda and q.shape[-1] in (16, 32) and eps == 1e-6 and q.shape[0] <= 65535:   # (grid.z = sample)
+def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6, hp=None):      # loftr_module/linear_attention.py:29-61
+    if hp is not None and q.is_cuda and q.shape[-1] in (16, 32) and eps == 1e-6 and q.shape[0] <= 65535:   # (grid.z = sample)
         return HipLinearAttention.apply(q, k, v, q_mask, kv_mask)
     Q, K = F.elu(q) + 1, F.elu(k) + 1
     if q_mask is not None:
@@ -198,37 +252,37 @@ def _linear_attention(q, k, v, q_mask=None, kv_mask=None, eps=1e-6):      # loft
     return torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S
 
 
-def _encoder_layer(p, name, nhead, x, source, x_mask=None, source_mask=None):      # loftr_module/transformer.py:65-94
+def _encoder_layer(p, name, nhead, x, source, x_mask=None, source_mask=None, hp=None):      # loftr_module/transformer.py:65-94
     B, _, C = x.shape
     D = C // nhead
     wq, wk, wv = p[name + ".q_proj.weight"], p[name + ".k_proj.weight"], p[name + ".v_proj.weight"]
-    if _HIP_LINEAR_PREC is not None and x.is_cuda:
+    if hp is not None and x.is_cuda:
         # projections that read the same tokens run as ONE Linear node on the stacked weight: its backward transposes / splits
         # the shared input once and reduces one [2C | 3C] x C weight gradient instead of two or three C x C ones
         if source is x:
-            q, k, v = _linear(x, torch.cat([wq, wk, wv], 0)).split(C, dim=2)
+            q, k, v = _linear(x, torch.cat([wq, wk, wv], 0), hp).split(C, dim=2)
         else:
-            q = _linear(x, wq)
-            k, v = _linear(source, torch.cat([wk, wv], 0)).split(C, dim=2)
+            q = _linear(x, wq, hp)
+            k, v = _linear(source, torch.cat([wk, wv], 0), hp).split(C, dim=2)
         q, k, v = (t.reshape(B, -1, nhead, D) for t in (q, k, v))
     else:
         q = _linear(x, wq).view(B, -1, nhead, D)
         k = _linear(source, wk).view(B, -1, nhead, D)
         v = _linear(source, wv).view(B, -1, nhead, D)
-    msg = _linear_attention(q, k, v, x_mask, source_mask).reshape(B, -1, C)
-    msg = F.layer_norm(_linear(msg, p[name + ".merge.weight"]), (C,), p[name + ".norm1.weight"], p[name + ".norm1.bias"], _EPS_LN)
-    msg = _linear(F.relu(_linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"])), p[name + ".mlp.2.weight"])
-    return x + F.layer_norm(msg, (C,), p[name + ".norm2.weight"], p[name + ".norm2.bias"], _EPS_LN)
+    msg = _linear_attention(q, k, v, x_mask, source_mask, hp=hp).reshape(B, -1, C)
+    msg = _layer_norm(_linear(msg, p[name + ".merge.weight"], hp), p[name + ".norm1.weight"], p[name + ".norm1.bias"], hp)
+    msg = _linear(F.relu(_linear(torch.cat([x, msg], dim=2), p[name + ".mlp.0.weight"], hp)), p[name + ".mlp.2.weight"], hp)
+    return x + _layer_norm(msg, p[name + ".norm2.weight"], p[name + ".norm2.bias"], hp)
 
 
-def _transformer(p, name, tcfg, f3, f2, mask=None):      # loftr_module/transformer.py:133-171 (f3 already [B, N, C])
+def _transformer(p, name, tcfg, f3, f2, mask=None, hp=None):      # loftr_module/transformer.py:133-171 (f3 already [B, N, C])
     for i, kind in enumerate(list(tcfg["layer_names"]) * tcfg["layer_iter_n"]):
         n = "%s.layers.%d" % (name, i)
         if kind == "self":
-            f2, f3 = _encoder_layer(p, n, tcfg["nhead"], f2, f2, mask, mask), _encoder_layer(p, n, tcfg["nhead"], f3, f3)
+            f2, f3 = _encoder_layer(p, n, tcfg["nhead"], f2, f2, mask, mask, hp), _encoder_layer(p, n, tcfg["nhead"], f3, f3, hp=hp)
         else:       # cross: both streams from the pre-update tensors (quirk q6)
-            f2, f3 = (_encoder_layer(p, n, tcfg["nhead"], f2, f3, x_mask=mask),
-                      _encoder_layer(p, n, tcfg["nhead"], f3, f2, source_mask=mask))
+            f2, f3 = (_encoder_layer(p, n, tcfg["nhead"], f2, f3, x_mask=mask, hp=hp),
+                      _encoder_layer(p, n, tcfg["nhead"], f3, f2, source_mask=mask, hp=hp))
     return f3, f2
 
 
@@ -312,77 +366,232 @@ def differentiable_forward(p, cfg, inputs, matches, pe, bn_eval_stats=None):
     return conf, torch.cat([coords, std[:, None]], -1)
 
 
-def leaves_on_device(params):
-    return len(params) > 0 and all(p.is_cuda for p in params)
 
 
-def _pe_on(model, device):
-    """the sine table of PositionEncodingSine (67 MB) on the parameters' device, uploaded once per module, not per step"""
-    if model.dense_pos_encoding is None:
-        return None
-    pe = model.dense_pos_encoding.pe
-    if pe.device == device:
-        return pe
-    rt = model.__dict__.get("_rt")
-    key = ("pe_full", str(device))
-    if rt is not None:
-        if rt.get(key) is None:
-            rt[key] = pe.to(device)
-        return rt[key]
-    return pe.to(device)
-
-
-class TrainForward(torch.autograd.Function):
-    """forward: the HIP train()-mode forward of `model` (fills `data` like the reference); returns the two outputs the
-    loss differentiates.  backward: gradients of those outputs w.r.t. the parameters by torch.autograd on
-    `differentiable_forward` (see the module docstring)."""
+# ---------------------------------------------------------------------------------------------------------------------------
+# device graph of the training step: nodes around the C ABI of libopp_hip.so (include/opp_hip.h)
+# ---------------------------------------------------------------------------------------------------------------------------
+class HipBackbone(torch.autograd.Function):
+    """ResNetFPN_8_2.forward in train() mode (backbone/resnet.py:141-164) on the HIP path, keeping its activations on a tape
+    (`opp_backbone_train_tape`), with the whole backward in libopp_hip.so (`opp_backbone_backward`: convolution input / weight
+    gradients, BatchNorm + activation backward, upsample transpose).  Returns feat_c [B, L, 256] and feat_f [B, Hf * Wf, 128]
+    (NHWC = token-major).  `table_idx[k]` = position of params[k] in the C context's weight table."""
 
     @staticmethod
-    def forward(ctx, model, data, names, *params):
-        with torch.no_grad():
-            model._forward_train(data)
-        ctx.model, ctx.names = model, names
+    def forward(ctx, model, img, table_idx, *params):
+        from . import _lib
+        dev = img.device
+        lib, c = model._ensure_ready(dev)
+        model._ensure_train_packed(lib, c, dev)
         cfg = model.config
-        ctx.inputs = {k: data[k] for k in ("query_image", "keypoints3d", "descriptors3d_db") if k in data}
-        ctx.inputs["descriptors3d_coarse_db"] = data.get("descriptors3d_coarse_db")
-        ctx.inputs["query_image_mask"] = data["query_image_mask"].flatten(-2).float() if "query_image_mask" in data else None
-        ctx.matches = (data["b_ids"], data["i_ids"], data["j_ids"])
-        ctx.has_fine = bool(cfg["fine_matching"]["enable"]) and "expec_f" in data
-        ctx.save_for_backward(*params)
-        expec = data["expec_f"] if ctx.has_fine else data["conf_matrix"].new_zeros(0, 3)
-        return data["conf_matrix"], expec
+        B, H, W = int(img.shape[0]), int(img.shape[2]), int(img.shape[3])
+        dC, dF = cfg["loftr_coarse"]["d_model"], cfg["loftr_fine"]["d_model"]
+        feat_c = torch.empty((B, (H // 8) * (W // 8), dC), dtype=torch.float32, device=dev)
+        feat_f = torch.empty((B, (H // 2) * (W // 2), dF), dtype=torch.float32, device=dev)
+        tape = torch.empty(lib.opp_backbone_tape_bytes(c, B, H, W), dtype=torch.uint8, device=dev)
+        ws = model._workspace(lib.opp_backbone_train_tape_workspace_bytes(c, B, H, W), dev)
+        n_bn = lib.opp_num_bn_layers(c)
+        stats = torch.zeros((n_bn, 512), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(lib.opp_backbone_train_tape(c, img.data_ptr(), B, H, W, feat_c.data_ptr(), feat_f.data_ptr(), stats.data_ptr(),
+                                               tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), stream), "opp_backbone_train_tape")
+        model._update_running_stats(lib, c, stats)
+        ctx.model, ctx.img, ctx.tape, ctx.table_idx = model, img, tape, table_idx
+        ctx.ptrs, ctx.keep = model._rt["ptrs"], model._rt["keep"]       # the weight table the tape's forward ran on (kept alive)
+        ctx.geom = (B, H, W)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return feat_c, feat_f
 
     @staticmethod
-    def backward(ctx, g_conf, g_expec):
+    def backward(ctx, g_fc, g_ff):
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
         model = ctx.model
-        params = ctx.saved_tensors
-        need = [ctx.needs_input_grad[3 + i] for i in range(len(params))]
-        global _HIP_LINEAR_PREC
-        prev_prec = _HIP_LINEAR_PREC
-        if leaves_on_device(params) and os.environ.get("OPP_TRAIN_HIP_LINEAR", "1") != "0":
-            _HIP_LINEAR_PREC = {"bf16x3": 2, "fp32": 0}.get(getattr(model, "gemm_precision", "bf16x3"), 2)
-        try:
-            return TrainForward._backward_impl(ctx, model, params, need, g_conf, g_expec)
-        finally:
-            _HIP_LINEAR_PREC = prev_prec
+        c = model._rt["ctx"]
+        dev = ctx.img.device
+        B, H, W = ctx.geom
+        ptrs, n = ctx.ptrs
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        gp = (ctypes.c_void_p * n)()
+        for k, i in enumerate(ctx.table_idx):
+            gp[i] = grads[k].data_ptr()
+        g_fc = g_fc.to(torch.float32).contiguous()
+        g_ff = g_ff.to(torch.float32).contiguous()
+        nb = lib.opp_backbone_backward_workspace_bytes(c, B, H, W)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_backbone_backward(c, ctx.img.data_ptr(), B, H, W, ctx.tape.data_ptr(), ctx.tape.numel(), ptrs, n, g_fc.data_ptr(),
+                                                 g_ff.data_ptr(), gp, ws.data_ptr(), nb, torch.cuda.current_stream(dev).cuda_stream),
+                       "opp_backbone_backward")
+        ctx.tape = None
+        return (None, None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[3:]))
+
+
+class HipCoarseMatch(torch.autograd.Function):
+    """CoarseMatching.forward (utils/coarse_matching.py:99-172) on the transformer outputs f3 [B, N, C] (3D points) and f2 [B, L, C]
+    (image cells): forward = the inference kernels, sample by sample (`opp_coarse_match`: score GEMM with the dual-softmax
+    statistics, confidences, mutual-nearest-neighbour selection); returns conf_matrix [B, N, L] and leaves the selection (i_all,
+    j_all, c_all, counts) in `aux`.  backward: the score matrix is recomputed by one GEMM per sample, `opp_dual_softmax_forward`
+    gives its log-sum-exps, `opp_dual_softmax_backward` the gradient of the scores, `opp_linear_backward` those of f3 and f2."""
 
     @staticmethod
-    def _backward_impl(ctx, model, params, need, g_conf, g_expec):
-        with torch.enable_grad():
-            leaves = [p.detach().requires_grad_(n) for p, n in zip(params, need)]
-            p = dict(zip(ctx.names, leaves))
-            pe = _pe_on(model, leaves[0].device)
-            frozen = bool(model.loftr_backbone_pretrained) and bool(model.config["loftr_backbone"]["pretrained_fix"])
-            stats = None
-            if frozen:       # OnePosePlusModel.py:109-113: the frozen backbone runs in eval mode
-                stats = {n[:-len(".running_mean")]: (b, dict(model.named_buffers())[n[:-len(".running_mean")] + ".running_var"])
-                         for n, b in model.named_buffers() if n.endswith(".running_mean")}
-            conf, expec = differentiable_forward(p, model.config, ctx.inputs, ctx.matches, pe, stats)
-            outs, gouts = [conf], [g_conf]
-            if ctx.has_fine and expec is not None and g_expec is not None:
-                outs.append(expec)
-                gouts.append(g_expec)
-            wanted = [l for l, n in zip(leaves, need) if n]
-            grads = torch.autograd.grad(outs, wanted, gouts, allow_unused=True) if wanted else ()
-        it = iter(grads)
-        return (None, None, None) + tuple(next(it) if n else None for n in need)
+    def forward(ctx, f3, f2, aux):
+        from . import _lib
+        model, lib, c = aux["model"], aux["lib"], aux["ctx"]
+        dev = f3.device
+        f3c, f2c = f3.to(torch.float32).contiguous(), f2.to(torch.float32).contiguous()
+        B, N, C = f3c.shape
+        L = f2c.shape[1]
+        hc, wc = aux["hc"], aux["wc"]
+        kpts, mask, qscale = aux["kpts"], aux["mask"], aux["qscale"]
+        conf = torch.empty((B, N, L), dtype=torch.float32, device=dev)
+        i_all = torch.empty((B, N), dtype=torch.int64, device=dev)
+        j_all = torch.empty((B, N), dtype=torch.int64, device=dev)
+        c_all = torch.empty((B, N), dtype=torch.float32, device=dev)
+        mkc = torch.empty((N, 2), dtype=torch.float32, device=dev)
+        mk3 = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+        ws = model._workspace(max(lib.opp_coarse_match_workspace_bytes(c, N, L), 4096), dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        try:
+            for b in range(B):
+                _lib.check(lib.opp_set_query_mask(c, mask[b].data_ptr() if mask is not None else None), "query_mask")
+                _lib.check(lib.opp_coarse_match(c, f3c[b].data_ptr(), f2c[b].data_ptr(), N, hc, wc, kpts[b].data_ptr(), aux["scale_c"],
+                                                qscale[b].data_ptr() if qscale is not None else None, conf[b].data_ptr(),
+                                                i_all[b].data_ptr(), j_all[b].data_ptr(), c_all[b].data_ptr(), mkc.data_ptr(),
+                                                mk3.data_ptr(), counts[b].data_ptr(), ws.data_ptr(), ws.numel(), stream), "opp_coarse_match")
+        finally:
+            lib.opp_set_query_mask(c, None)
+        aux.update({"i_all": i_all, "j_all": j_all, "c_all": c_all, "counts": counts})
+        ctx.save_for_backward(f3c, f2c)
+        ctx.mask, ctx.hp = mask, aux["hp"]
+        ctx.scale = (1.0 / C) / (float(model.config["coarse_matching"]["dual_softmax"]["temperature"]) + 1e-4)
+        return conf
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        f3, f2 = ctx.saved_tensors
+        dev = f3.device
+        B, N, C = f3.shape
+        L = f2.shape[1]
+        hp = ctx.hp
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        sim = torch.empty((B, N, L), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            wop = torch.empty(L * C // 2 * 3, dtype=torch.float32, device=dev) if hp == 2 else None
+            for b in range(B):
+                w = f2[b]
+                if hp == 2:
+                    _lib.check(lib.opp_pack_b3(f2[b].data_ptr(), wop.data_ptr(), L * C, stream), "opp_pack_b3")
+                    w = wop
+                _lib.check(lib.opp_linear(f3[b].data_ptr(), N, C, w.data_ptr(), L, 0, sim[b].data_ptr(), -1, hp, None, stream), "opp_linear")
+            sim.mul_(ctx.scale)
+            if ctx.mask is not None:                                    # coarse_matching.py:108-114
+                sim.add_(torch.where(ctx.mask[:, None].bool(), 0.0, -1e9).to(sim.dtype))
+            lse_row = torch.empty((B, N), dtype=torch.float32, device=dev)
+            lse_col = torch.empty((B, L), dtype=torch.float32, device=dev)
+            nb = max(lib.opp_dual_softmax_forward_workspace_bytes(B, N, L), lib.opp_dual_softmax_backward_workspace_bytes(B, N, L),
+                     lib.opp_linear_backward_workspace_bytes(N, L, C, hp))
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.opp_dual_softmax_forward(sim.data_ptr(), B, N, L, lse_row.data_ptr(), lse_col.data_ptr(), None, ws.data_ptr(), nb, stream),
+                       "opp_dual_softmax_forward")
+            gc = g.to(torch.float32).contiguous()
+            ds = torch.empty_like(sim)
+            _lib.check(lib.opp_dual_softmax_backward(gc.data_ptr(), sim.data_ptr(), lse_row.data_ptr(), lse_col.data_ptr(), B, N, L, ds.data_ptr(),
+                                                     ws.data_ptr(), nb, stream), "opp_dual_softmax_backward")
+            ds.mul_(ctx.scale)
+            g3, g2 = torch.empty_like(f3), torch.empty_like(f2)
+            for b in range(B):                                          # sim_b = f3_b f2_b^T: a Linear with x = f3_b, W = f2_b
+                _lib.check(lib.opp_linear_backward(ds[b].data_ptr(), f3[b].data_ptr(), f2[b].data_ptr(), N, L, C, g3[b].data_ptr(), g2[b].data_ptr(),
+                                                   0, hp, ws.data_ptr(), nb, stream), "opp_linear_backward")
+        return g3, g2, None
+
+
+class HipFineGather(torch.autograd.Function):
+    """FinePreprocess (loftr_module/fine_preprocess.py:41-55): the W x W window of the fine map around every selected coarse cell,
+    straight from the NHWC map (no unfold matrix): feat_f [B, Hf * Wf, C] -> windows [M, W * W, C]; the backward adds the window
+    gradients back into the map (`opp_fine_window_gather_backward`)."""
+
+    @staticmethod
+    def forward(ctx, feat_f, b_ids, j_ids, geom):
+        from . import _lib
+        lib = _lib.load()
+        B, Hf, Wf, hc, wc, W = geom
+        dev = feat_f.device
+        ff = feat_f.to(torch.float32).contiguous()
+        C = ff.shape[-1]
+        bi, ji = b_ids.to(torch.int64).contiguous(), j_ids.to(torch.int64).contiguous()
+        M = int(bi.numel())
+        win = torch.empty((M, W * W, C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_fine_window_gather(ff.data_ptr(), B, Hf, Wf, C, bi.data_ptr(), ji.data_ptr(), M, hc, wc, W, win.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "opp_fine_window_gather")
+        ctx.save_for_backward(bi, ji)
+        ctx.geom, ctx.C, ctx.shape = geom, C, tuple(feat_f.shape)
+        return win
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        bi, ji = ctx.saved_tensors
+        B, Hf, Wf, hc, wc, W = ctx.geom
+        dev = g.device
+        gc = g.to(torch.float32).contiguous()
+        d = torch.empty((B, Hf * Wf, ctx.C), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_fine_window_gather_backward(gc.data_ptr(), B, Hf, Wf, ctx.C, bi.data_ptr(), ji.data_ptr(), int(bi.numel()), hc, wc, W,
+                                                           d.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "opp_fine_window_gather_backward")
+        return d.view(ctx.shape), None, None, None
+
+
+def graph_precision(model):
+    """`hp` of the device graph from the module's gemm_precision"""
+    return {"bf16x3": 2, "fp32": 0}[model.gemm_precision]
+
+
+def backbone_node(model, lib, c, img):
+    """feat_c [B, L, dC], feat_f [B, Hf * Wf, dF] with a grad_fn (`HipBackbone`)"""
+    names = model._rt["names"]
+    params = dict(model.named_parameters())
+    idx = [i for i, n in enumerate(names) if n.startswith("backbone.") and n in params]
+    return HipBackbone.apply(model, img, tuple(idx), *[params[names[i]] for i in idx])
+
+
+def coarse_level_graph(model, lib, c, p, feat_c, pe, kpts, bank_c, mask, qscale, hc, wc, scale_c):
+    """tokens (OnePosePlusModel.py:137-156) -> loftr_coarse -> CoarseMatching: conf_matrix [B, N, L] with a grad_fn + the selection"""
+    cfg = model.config
+    hp = graph_precision(model)
+    tokens2d = feat_c + pe[None] if pe is not None else feat_c               # PositionEncodingSine on the NHWC tokens
+    if cfg["keypoints_encoding"]["enable"]:
+        tokens3d = _kpt_encoding(p, kpts, bank_c, hp).transpose(1, 2)
+    else:
+        tokens3d = bank_c.transpose(1, 2)
+    f3, f2 = _transformer(p, "loftr_coarse", cfg["loftr_coarse"], tokens3d.contiguous(), tokens2d, mask, hp)
+    aux = {"model": model, "lib": lib, "ctx": c, "hc": hc, "wc": wc, "kpts": kpts, "mask": mask, "qscale": qscale, "scale_c": scale_c, "hp": hp}
+    conf = HipCoarseMatch.apply(f3, f2, aux)
+    return conf, aux
+
+
+def fine_level_graph(model, p, feat_f, bank_f, b_ids, i_ids, j_ids, B, hf, wf, hc, wc):
+    """FinePreprocess -> loftr_fine -> FineMatching._s2d_heatmap (fine_preprocess.py:41-55, fine_matching.py:63-94): expec_f [M, 3]"""
+    cfg = model.config
+    hp = graph_precision(model)
+    fcfg = cfg["loftr_fine"]
+    W, Cf = fcfg["window_size"], fcfg["d_model"]
+    win = HipFineGather.apply(feat_f, b_ids, j_ids, (B, hf, wf, hc, wc, W))           # [M, WW, C]
+    g3 = bank_f.permute(0, 2, 1)[b_ids, i_ids].unsqueeze(1)                           # [M, 1, C]: the RAW fine bank (quirk q8)
+    if fcfg["enable"]:
+        g3, win = _transformer(p, "loftr_fine", fcfg, g3.contiguous(), win, None, hp)
+    f0 = g3[:, g3.shape[1] // 2, :]                                                   # fine_matching.py:63-68
+    heat = torch.softmax((f0[:, None, :] * win).sum(-1) / Cf ** 0.5, dim=1)           # 'mc,mrc->mr' as multiply + reduce
+    lin = (torch.linspace(0, W - 1, W, device=heat.device) / (W - 1) - 0.5) * 2
+    gx, gy = lin.view(1, W).expand(W, W).reshape(-1), lin.view(W, 1).expand(W, W).reshape(-1)
+    coords = torch.stack([(gx * heat).sum(-1), (gy * heat).sum(-1)], dim=-1)
+    grid = torch.stack([gx, gy], dim=-1)
+    var = torch.sum(grid[None] ** 2 * heat[:, :, None], dim=1) - coords ** 2
+    std = torch.sum(torch.sqrt(torch.clamp(var, min=1e-10)), -1)                      # fine_matching.py:92-94
+    return torch.cat([coords, std[:, None]], -1)

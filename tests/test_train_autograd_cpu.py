@@ -30,13 +30,27 @@ def test_differentiable_forward_matches_reference_gradients(name):
 
 
 def test_autograd_function_is_wired_into_training_mode():
-    """train() + gradients enabled routes through TrainForward (no GPU here: the HIP forward itself is covered by
-    tests/test_e2e_gpu.py::test_training_step_gradients)."""
+    """train() + gradients enabled builds the graph of HIP nodes (no GPU here: the graph itself is covered by
+    tests/test_e2e_gpu.py::test_training_step_gradients and tests/test_train_bwd_gpu.py); CPU tensors are refused, and the
+    re-evaluating TrainForward of earlier rounds is gone."""
     from onepose_plus_plus_amd import OnePosePlus_model, default_config
     m = OnePosePlus_model(default_config()).train()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m({"query_image": torch.zeros(2, 1, 64, 64)})
-    assert hasattr(TA.TrainForward, "apply")
+    for node in ("HipBackbone", "HipLinear", "HipLinearAttention", "HipLayerNorm", "HipCoarseMatch", "HipFineGather"):
+        assert hasattr(getattr(TA, node), "apply")
+    assert not hasattr(TA, "TrainForward")
+
+
+def test_graph_helpers_fall_back_to_torch_ops_on_cpu_tensors_only_in_the_restatement():
+    """`hp = None` (the CPU restatement) never touches the HIP library; with `hp` set, CPU tensors still take the torch branch of
+    each helper (the device graph itself only ever passes device tensors)."""
+    x = torch.randn(2, 5, 64)
+    w = torch.randn(32, 64)
+    assert torch.equal(TA._linear(x, w), torch.nn.functional.linear(x, w))
+    assert torch.equal(TA._linear(x, w, 2), torch.nn.functional.linear(x, w))
+    g, b = torch.rand(64), torch.rand(64)
+    assert torch.equal(TA._layer_norm(x, g, b, 2), torch.nn.functional.layer_norm(x, (64,), g, b, 1e-5))
 
 
 def test_dual_softmax_formula_matches_autograd():

@@ -1,0 +1,292 @@
+"""GPU: the hand-written backward kernels of the training step (csrc/conv_bwd.hip, csrc/train_misc.hip and the
+graph nodes of onepose_plus_plus_amd/train_autograd.py), each through the C ABI against torch.autograd in fp64 on the CPU --
+the checker, never the product (backbone/resnet.py:10-45, :101-164; loftr_module/transformer.py:87-94;
+utils/coarse_matching.py:115; loftr_module/fine_preprocess.py:41-55)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def _nhwc(x, c_pad):
+    """[B, C, H, W] -> device NHWC [B, H, W, c_pad] with zero padding channels"""
+    b, c, h, w = x.shape
+    out = torch.zeros(b, h, w, c_pad)
+    out[..., :c] = x.permute(0, 2, 3, 1)
+    return out.cuda().contiguous()
+
+
+def _from_nhwc(y, c):
+    return y[..., :c].permute(0, 3, 1, 2).cpu()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+@pytest.mark.parametrize("prec", [2, 0])
+@pytest.mark.parametrize("B,cin,cout,ks,stride,H,W", [
+    (2, 128, 128, 3, 1, 16, 24),      # layer1-style
+    (1, 128, 196, 3, 2, 16, 16),      # layer2.0.conv1: stride 2, 196 (-> 224) output channels
+    (2, 196, 196, 3, 1, 8, 12),       # K tail packing on the input-gradient convolution, two channel tiles
+    (1, 128, 196, 1, 2, 16, 16),      # downsample 1x1 stride 2
+    (2, 196, 256, 1, 1, 8, 8),        # lateral 1x1
+    (1, 256, 256, 3, 1, 8, 8),
+    (3, 64, 96, 3, 1, 5, 7),          # ragged sizes: pixel count not a multiple of 32
+])
+def test_conv2d_backward_vs_autograd(B, cin, cout, ks, stride, H, W, prec):
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + cin + cout + ks + stride)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) / (cin * ks * ks) ** 0.5
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y = F.conv2d(xd, wd, None, stride, ks // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.double())
+    cin_p, cout_p = _pad32(cin), _pad32(cout)
+    xn, gyn, wdev = _nhwc(x, cin_p), _nhwc(gy, cout_p), w.cuda().contiguous()
+    gx = torch.full((B, H, W, cin_p), float("nan"), device="cuda")
+    gw = torch.full((cout, cin, ks, ks), float("nan"), device="cuda")
+    nb = lib.opp_conv2d_backward_workspace_bytes(B, H, W, cin, cout, ks, stride, prec)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), gx.data_ptr(),
+                                            gw.data_ptr(), prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
+    torch.cuda.synchronize()
+    assert _rel(_from_nhwc(gx, cin), xd.grad) < 2e-6, "grad_x"
+    assert (gx[..., cin:] == 0).all(), "padded channels of grad_x must be exact zeros"
+    assert _rel(gw.cpu(), wd.grad) < 2e-6, "grad_w"
+    # deterministic: fixed-order split reduction
+    gw2 = torch.empty_like(gw)
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), None,
+                                            gw2.data_ptr(), prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
+    torch.cuda.synchronize()
+    assert torch.equal(gw, gw2)
+
+
+def test_conv_wgrad_long_reduction():
+    """the reduction length of the real step (tens of thousands of pixels per split chain) keeps fp32-level accuracy"""
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    B, cin, cout, H, W = 2, 64, 64, 96, 128
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    xd, wd = x.double(), w.double().requires_grad_(True)
+    F.conv2d(xd, wd, None, 1, 1).backward(gy.double())
+    xn, gyn = _nhwc(x, cin), _nhwc(gy, cout)
+    gw = torch.empty((cout, cin, 3, 3), device="cuda")
+    nb = lib.opp_conv2d_backward_workspace_bytes(B, H, W, cin, cout, 3, 1, 2)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, w.cuda().data_ptr(), cout, 3, 1, gyn.data_ptr(), None, gw.data_ptr(), 2,
+                                            ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
+    torch.cuda.synchronize()
+    # error relative to sum |a||b| ~ sqrt(P) * 0.64: a few fp32 ulps of the largest partial sums
+    assert float((gw.cpu().double() - wd.grad).abs().max()) < 3e-6 * (B * H * W) ** 0.5
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("rows,C,with_res", [(700, 128, True), (513, 196, False), (64, 256, True)])
+def test_batchnorm_backward_vs_autograd(rows, C, act, with_res):
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    ld = _pad32(C)
+    g = torch.Generator().manual_seed(rows + C + act)
+    raw = torch.randn(rows, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    res = torch.randn(rows, C, generator=g) if with_res else None
+    gy = torch.randn(rows, C, generator=g)
+    rd, gd, bd = raw.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    resd = res.double().requires_grad_(True) if with_res else None
+    mean = rd.mean(0)
+    var = rd.var(0, unbiased=False)
+    z = (rd - mean) / torch.sqrt(var + 1e-5) * gd + bd
+    if with_res:
+        z = z + resd
+    y = F.relu(z) if act == 1 else F.leaky_relu(z, 0.01) if act == 2 else z
+    y.backward(gy.double())
+
+    def padded(t):
+        o = torch.zeros(rows, ld)
+        o[:, :C] = t
+        return o.cuda()
+    pm, pi = torch.zeros(ld), torch.zeros(ld)
+    pm[:C] = mean.detach().float()
+    pi[:C] = (1.0 / torch.sqrt(var.detach() + 1e-5)).float()
+    gyn, yn, rawn = padded(gy), padded(y.detach().float()), padded(raw)
+    d_raw = torch.full((rows, ld), float("nan"), device="cuda")
+    d_res = torch.full((rows, ld), float("nan"), device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    nb = lib.opp_batchnorm_backward_workspace_bytes(rows, ld)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_batchnorm_backward_nhwc(gyn.data_ptr(), yn.data_ptr(), rawn.data_ptr(), rows, ld, C, act, gamma.cuda().data_ptr(),
+                                               pm.cuda().data_ptr(), pi.cuda().data_ptr(), d_raw.data_ptr(), d_res.data_ptr(), dg.data_ptr(),
+                                               db.data_ptr(), ws.data_ptr(), nb, _s()), "opp_batchnorm_backward_nhwc")
+    torch.cuda.synchronize()
+    assert _rel(d_raw[:, :C].cpu(), rd.grad) < 1e-5
+    assert (d_raw[:, C:] == 0).all()
+    assert _rel(dg.cpu(), gd.grad) < 1e-5 and _rel(db.cpu(), bd.grad) < 1e-5
+    if with_res:
+        assert _rel(d_res[:, :C].cpu(), resd.grad) < 1e-6
+
+
+@pytest.mark.parametrize("B,Hr,Wr,C", [(2, 4, 6, 32), (1, 1, 3, 64), (1, 16, 16, 224)])
+def test_upsample2x_backward_vs_autograd(B, Hr, Wr, C):
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Hr * 10 + Wr)
+    r = torch.randn(B, C, Hr, Wr, generator=g).double().requires_grad_(True)
+    up = F.interpolate(r, scale_factor=2.0, mode="bilinear", align_corners=True)
+    go = torch.randn(up.shape, generator=g)
+    up.backward(go.double())
+    gon = _nhwc(go, C)
+    base = torch.randn(B, Hr, Wr, C, generator=g).cuda()
+    for acc in (0, 1):
+        out = base.clone()
+        _lib.check(lib.opp_upsample2x_backward_nhwc(gon.data_ptr(), B, Hr, Wr, C, out.data_ptr(), acc, _s()), "opp_upsample2x_backward_nhwc")
+        torch.cuda.synchronize()
+        want = r.grad.permute(0, 2, 3, 1) + (base.cpu().double() if acc else 0)
+        assert float((out.cpu().double() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 256), (77, 128), (5, 64)])
+def test_layer_norm_node_vs_autograd(rows, C):
+    from onepose_plus_plus_amd.train_autograd import HipLayerNorm
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, C, generator=g) * 3 + 1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    go = torch.randn(rows, C, generator=g)
+    xd, gd, bd = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    F.layer_norm(xd, (C,), gd, bd, 1e-5).backward(go.double())
+    xc, gc, bc = (t.cuda().requires_grad_(True) for t in (x, gamma, beta))
+    y = HipLayerNorm.apply(xc.view(1, rows, C), gc, bc)
+    assert _rel(y.detach().cpu().view(rows, C), F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5)) < 2e-6
+    y.backward(go.cuda().view(1, rows, C))
+    torch.cuda.synchronize()
+    assert _rel(xc.grad.cpu(), xd.grad) < 1e-5 and _rel(gc.grad.cpu(), gd.grad) < 1e-5 and _rel(bc.grad.cpu(), bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,L", [(2, 150, 96), (1, 333, 260), (3, 17, 8)])
+def test_dual_softmax_forward_lse_and_conf(B, N, L):
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N)
+    S = torch.randn(B, N, L, generator=g) * 4
+    S[0, :, :2] -= 1e9                                      # masked cells
+    Sd = S.double()
+    Sc = S.cuda()
+    lr, lc = torch.empty(B, N, device="cuda"), torch.empty(B, L, device="cuda")
+    conf = torch.empty(B, N, L, device="cuda")
+    nb = lib.opp_dual_softmax_forward_workspace_bytes(B, N, L)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_dual_softmax_forward(Sc.data_ptr(), B, N, L, lr.data_ptr(), lc.data_ptr(), conf.data_ptr() if L % 4 == 0 else None,
+                                            ws.data_ptr(), nb, _s()), "opp_dual_softmax_forward")
+    torch.cuda.synchronize()
+    for got, want in ((lr, torch.logsumexp(Sd, 2)), (lc, torch.logsumexp(Sd, 1))):
+        assert float(((got.cpu().double() - want).abs() / want.abs().clamp(min=1)).max()) < 2e-6
+    if L % 4 == 0:
+        want = F.softmax(Sd, 1) * F.softmax(Sd, 2)
+        assert float((conf.cpu().double() - want).abs().max()) < 2e-6
+
+
+def test_fine_window_gather_node_vs_unfold():
+    from onepose_plus_plus_amd.train_autograd import HipFineGather
+    B, C, Hf, Wf, hc, wc, W = 2, 128, 16, 24, 4, 6, 5
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(B, C, Hf, Wf, generator=g)
+    M = 40
+    b_ids = torch.randint(0, B, (M,), generator=g)
+    j_ids = torch.randint(0, hc * wc, (M,), generator=g)
+    j_ids[:4] = torch.tensor([0, wc - 1, hc * wc - 1, (hc - 1) * wc])      # image corners: windows reach outside
+    j_ids[5] = j_ids[6]                                                      # duplicates (ground-truth padding repeats cells)
+    b_ids[5] = b_ids[6]
+    fd = feat.double().requires_grad_(True)
+    un = F.unfold(fd, kernel_size=(W, W), stride=Hf // hc, padding=W // 2).view(B, C, W * W, -1).permute(0, 3, 2, 1)[b_ids, j_ids]
+    go = torch.randn(un.shape, generator=g)
+    un.backward(go.double())
+    fc = feat.permute(0, 2, 3, 1).reshape(B, Hf * Wf, C).contiguous().cuda().requires_grad_(True)
+    win = HipFineGather.apply(fc, b_ids.cuda(), j_ids.cuda(), (B, Hf, Wf, hc, wc, W))
+    assert torch.equal(win.detach().cpu().double(), un.detach())
+    win.backward(go.cuda())
+    torch.cuda.synchronize()
+    want = fd.grad.permute(0, 2, 3, 1).reshape(B, Hf * Wf, C)
+    assert float((fc.grad.cpu().double() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_backbone_node_vs_autograd(precision):
+    """`HipBackbone` (taped train-mode forward + opp_backbone_backward) against torch.autograd of the functional restatement
+    `train_autograd._backbone` in fp64 on the CPU: both outputs and the gradient of every backbone parameter."""
+    from onepose_plus_plus_amd import train_autograd as TA
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    from tests import hip_ops as ops
+    cfg = default_config()
+    sd = make_state_dict(cfg, 4)
+    model = ops.make_model(cfg, sd, precision)
+    model.train()
+    B, H, W = 2, 64, 96
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(B, 1, H, W, generator=g)
+    lib, c = model._ensure_ready(torch.device("cuda:0"))
+    fc, ff = TA.backbone_node(model, lib, c, img.cuda().contiguous())
+    gfc, gff = torch.randn(fc.shape, generator=g), torch.randn(ff.shape, generator=g)
+    (fc * gfc.cuda()).sum().add((ff * gff.cuda()).sum()).backward()
+    torch.cuda.synchronize()
+    p = {k: v.double().requires_grad_(k.startswith("backbone.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+         for k, v in sd.items() if v.is_floating_point()}
+    rc, rf = TA._backbone(p, img.double())
+    rc_t = rc.flatten(2).transpose(1, 2)
+    rf_t = rf.flatten(2).transpose(1, 2)
+    assert _rel(fc.detach().cpu(), rc_t.detach()) < 1e-5 and _rel(ff.detach().cpu(), rf_t.detach()) < 1e-5
+    ((rc_t * gfc.double()).sum() + (rf_t * gff.double()).sum()).backward()
+    bad = []
+    n = 0
+    n_expect = sum(1 for k in sd if k.startswith("backbone.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
+    for name, prm in model.named_parameters():
+        if not name.startswith("backbone."):
+            assert prm.grad is None
+            continue
+        n += 1
+        want = p[name].grad
+        err = float((prm.grad.cpu().double() - want).abs().max())
+        if err > 1e-4 * float(want.abs().max()) + 1e-9:
+            bad.append((name, err, float(want.abs().max())))
+    assert n == n_expect and n > 50 and not bad, bad[:8]
+
+
+@pytest.mark.parametrize("M,N,K", [(9096, 768, 256), (1000, 256, 512), (77, 128, 128)])
+def test_linear_weight_gradient_on_the_pixel_major_kernel(M, N, K):
+    """opp_linear_backward (bf16x3) now forms dW on conv_wgrad_kernel straight from the token-major operands"""
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M)
+    x, gy, w = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g), torch.randn(N, K, generator=g)
+    want_w = gy.double().t() @ x.double()
+    want_x = gy.double() @ w.double()
+    xc, gc, wc = x.cuda(), gy.cuda(), w.cuda()
+    dx, dw = torch.empty(M, K, device="cuda"), torch.empty(N, K, device="cuda")
+    nb = lib.opp_linear_backward_workspace_bytes(M, N, K, 2)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.opp_linear_backward(gc.data_ptr(), xc.data_ptr(), wc.data_ptr(), M, N, K, dx.data_ptr(), dw.data_ptr(), 0, 2, ws.data_ptr(), nb, _s()),
+               "opp_linear_backward")
+    torch.cuda.synchronize()
+    assert float((dw.cpu().double() - want_w).abs().max()) < 3e-6 * M ** 0.5
+    assert float((dx.cpu().double() - want_x).abs().max()) < 3e-6 * N ** 0.5
+    dw2 = dw.clone()
+    _lib.check(lib.opp_linear_backward(gc.data_ptr(), xc.data_ptr(), wc.data_ptr(), M, N, K, None, dw2.data_ptr(), 1, 2, ws.data_ptr(), nb, _s()),
+               "opp_linear_backward")
+    torch.cuda.synchronize()
+    assert float((dw2.cpu().double() - 2 * want_w).abs().max()) < 6e-6 * M ** 0.5      # accumulate_grad_w
