@@ -61,6 +61,7 @@ SIGNATURES = {
     "opp_backbone_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "opp_backbone_train": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_packed_weights_bytes": (c_size_t, [c_void_p]),
+    "opp_set_pack_scope": (c_int, [c_void_p, c_int]),
     "opp_pack_weights": (c_int, [c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     "opp_backbone_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "opp_backbone": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

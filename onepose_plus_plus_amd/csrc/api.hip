@@ -103,6 +103,10 @@ struct opp_ctx {
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
   bool train_packed = false;
+  // opp_set_pack_scope: 0 = opp_pack_weights lays out everything; 1 = the backbone only (the training graph reads the transformer /
+  // keypoint-encoder parameters directly): `tr_packed` says whether the packed blob holds the transformer + keypoint-MLP weights
+  int pack_scope = 0;
+  bool tr_packed = false;
   // fine-branch overlap of opp_forward_coarse (opp_config.fpn_overlap): a side stream and two events, created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -411,7 +415,8 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     }
     OPP_TRY(opp_pack_conv(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), d->w, s));
   }
-  if (c->cfg.kpt_enc_enable) {
+  const bool with_tr = c->pack_scope == 0;
+  if (c->cfg.kpt_enc_enable && with_tr) {
     const int ch[5] = {3, c->cfg.kpt_enc_dims[0], c->cfg.kpt_enc_dims[1], c->cfg.kpt_enc_dims[2], c->cfg.coarse_d_model};
     for (int i = 0; i < 4; ++i) {
       // PyTorch Linear weight [Cout][Cin] -> [Cin][Cout]
@@ -441,8 +446,10 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     }
     return OPP_OK;
   };
-  OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
-  OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
+  if (with_tr) {
+    OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
+    OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
+  }
   if (c->cfg.gemm_precision) {   // pre-split every GEMM weight matrix: fp16 hi/lo (same footprint) or bf16 hi/mid/lo (1.5x)
     const int prec = gemm_prec(c->cfg);
     auto split = [&](float* wm, size_t n, float* sc) -> int {
@@ -454,6 +461,7 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     for (ConvDesc* d : all_convs(c)) OPP_TRY(split(d->w, d->w_floats(), d->h2s));
     for (auto* L : {&c->coarse, &c->fine}) {
       const size_t d = (L == &c->coarse) ? c->cfg.coarse_d_model : c->cfg.fine_d_model;
+      if (!with_tr) break;
       for (auto& e : *L) {
         OPP_TRY(split(e.wqkv, 3 * d * d, e.sqkv));
         OPP_TRY(split(e.wmerge, d * d, e.smerge));
@@ -463,7 +471,14 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     }
   }
   c->packed = true;
+  c->tr_packed = with_tr;
   c->packed_bytes = need;
+  return OPP_OK;
+}
+
+extern "C" int opp_set_pack_scope(opp_ctx* ctx, int scope) {
+  OPP_CHECK_ARG(ctx && (scope == 0 || scope == 1), "set_pack_scope: scope must be 0 (everything) or 1 (backbone only)");
+  ctx->pack_scope = scope;
   return OPP_OK;
 }
 
@@ -528,9 +543,20 @@ extern "C" int opp_pack_train_weights(opp_ctx* c, const float* const* w, int n, 
 // ----------------------------------------------------------------------------------------
 namespace {
 
+// split-K scratch of the convolutions this host thread is enqueuing (backbone_impl sets it per stream branch; null = never split)
+constexpr size_t kSplitKScratchFloats = (size_t)4 << 20;      // 4 slices of <= 64 tiles of 128 x 128
+thread_local float* t_splitk_ws = nullptr;
+struct SplitKScope {
+  float* prev;
+  explicit SplitKScope(float* ws) : prev(t_splitk_ws) { t_splitk_ws = ws; }
+  ~SplitKScope() { t_splitk_ws = prev; }
+};
+
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
              float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false) {
   OppGemm g;
+  g.splitk_ws = t_splitk_ws;
+  g.splitk_ws_floats = t_splitk_ws ? kSplitKScratchFloats : 0;
   g.nonfinite = t_status_flag;
   g.tile_policy = t_tile_policy;
   g.conv = 1;
@@ -588,6 +614,7 @@ int run_block(const float* x, int Hin, int Win, const BlockDesc& b, int stride, 
 
 struct BackboneBufs {
   float *col, *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *l2, *u2, *x2o, *l1, *u1;
+  float *sk1 = nullptr, *sk2 = nullptr;   // split-K scratch of the two stream branches (they may run concurrently: opp_config.fpn_overlap)
 };
 
 size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) {
@@ -611,6 +638,8 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
   b.x2o = a.f(p4 * c2);
   b.l1 = a.f(p2 * c2);
   b.u1 = a.f(p2 * c2);
+  b.sk1 = a.f(kSplitKScratchFloats);
+  b.sk2 = a.f(kSplitKScratchFloats);
   return a.off;
 }
 
@@ -632,9 +661,11 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   const int hp = gemm_prec(c->cfg);
   if (phase != 2) {
+    SplitKScope sk_scope(b.sk1);
     // stem: conv7x7/s2 + BN + ReLU (resnet.py:143): one direct kernel (bf16x3), else im2col + GEMM -- bit-identical
     const char* stem_env = getenv("OPP_STEM_DIRECT");          // A/B switch of the tests / tools
-    if (opp_stem_direct_ok(c->stem.cout, hp) && pad32(c->stem.cout) == c->stem.cout && !(stem_env && stem_env[0] == '0')) {
+    if (opp_stem_direct_ok(c->stem.cout, hp) && pad32(c->stem.cout) == c->stem.cout && !(stem_env && stem_env[0] == '0') &&
+        (size_t)H2 * W2 * pad32(c->stem.cout) < (1ull << 31)) {
       OPP_TRY(opp_stem_direct(image, H, W, c->stem.w, c->stem.bias, b.x0, pad32(c->stem.cout), s));
     } else {
       OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
@@ -668,6 +699,7 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
   }
   if (phase != 1) {
+    SplitKScope sk_scope(b.sk2);
     OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
     OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
     OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
@@ -1448,6 +1480,7 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
 extern "C" int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float* pe, int L, const float* kpts,
                                  const float* bank_c, int n, float* tokens, void* ws, size_t ws_bytes, void* stream) {
   OPP_CHECK_ARG(ctx && ctx->packed && feat_c && kpts && bank_c && tokens && ws, "coarse_tokens: null argument");
+  OPP_CHECK_ARG(ctx->tr_packed, "coarse_tokens: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(L > 0 && n > 0, "coarse_tokens: empty input");
   Arena a(ws, ws_bytes);
   return coarse_tokens_impl(ctx, feat_c, pe, L, kpts, bank_c, n, nullptr, tokens, a, (hipStream_t)stream);
@@ -1456,6 +1489,7 @@ extern "C" int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float*
 extern "C" int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* bank_c, int n, float* tokens3d, void* ws,
                                  size_t ws_bytes, void* stream) {
   OPP_CHECK_ARG(ctx && ctx->packed && kpts && bank_c && tokens3d && ws && n > 0, "encode_points: bad argument");
+  OPP_CHECK_ARG(ctx->tr_packed, "encode_points: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   Arena a(ws, ws_bytes);
   return encode_points_impl(ctx, kpts, bank_c, n, tokens3d, a, (hipStream_t)stream);
 }
@@ -1503,6 +1537,7 @@ extern "C" int opp_transformer(opp_ctx* ctx, int which, float* tokens, int n_seg
                                size_t ws_bytes, void* stream) {
   FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && ctx->packed && tokens && ws, "transformer: null argument");
+  OPP_CHECK_ARG(ctx->tr_packed, "transformer: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(which == 0 || which == 1, "transformer: which must be 0 or 1");
   Arena a(ws, ws_bytes);
   if (which == 0)
@@ -1525,7 +1560,9 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
   float* stats = a.f(opp_coarse_match_stats_floats(n, L));
   const int sprec = score_prec(c->cfg);                // score GEMM on the split-operand path as well
   float* f2_split = sprec != OPP_PREC_FP32 ? a.f(split_floats((size_t)L * C, sprec)) : nullptr;
-  const bool two_sweep = sprec == OPP_PREC_BF16X3 && c->cfg.score_two_sweep && C % 32 == 0;
+  // (the split-operand core addresses its operands and output with 32-bit offsets: beyond that the r02 path reports the limit)
+  const bool two_sweep = sprec == OPP_PREC_BF16X3 && c->cfg.score_two_sweep && C % 32 == 0 && (size_t)n * L < (1ull << 31) &&
+                         (size_t)(n > L ? n : L) * C * 6 < (1ull << 31);
   float* f3_split = two_sweep ? a.f(split_floats((size_t)n * C, sprec)) : nullptr;
   if (!a.ok) {
     opp_set_error("coarse_match: workspace too small");
@@ -1643,6 +1680,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
                                   int* count, void* ws, size_t ws_bytes, void* stream) {
   FlagScope flag_scope(ctx);
   OPP_CHECK_ARG(ctx && ctx->packed && image && kpts && (bank_c || tokens3d_pre) && conf && ws, "forward_coarse: null argument");
+  OPP_CHECK_ARG(ctx->tr_packed, "forward_coarse: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(n > 0, "forward_coarse: empty point cloud");
   OPP_CHECK_ARG(!ctx->cfg.pos_enc_enable || pe, "forward_coarse: positional encoding enabled but pe is null");
   hipStream_t s = (hipStream_t)stream;
@@ -1666,24 +1704,43 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
     // coarse map; the FPN fine branch (six chip-filling convolutions, ~40 % of the backbone FLOPs) is needed by the fine
     // stage only.  Run the fine branch on a side stream next to the coarse level: fork after layer3_outconv, join below.
     if (!ctx->side_stream) {
-      if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
-          hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+      // all three objects or none: a half-built set must never be seen by a later call
+      hipStream_t st = nullptr;
+      hipEvent_t ef = nullptr, ej = nullptr;
+      const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        if (ej) (void)hipEventDestroy(ej);
+        if (ef) (void)hipEventDestroy(ef);
+        if (st) (void)hipStreamDestroy(st);
         opp_set_error("forward_coarse: cannot create the side stream of the fine-branch overlap");
         return OPP_ERR_LAUNCH;
       }
+      ctx->side_stream = st;
+      ctx->ev_fork = ef;
+      ctx->ev_join = ej;
     }
     BackboneBufs bufs;
     OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 1, &bufs));
     mark = a.off;                                    // the backbone buffers stay alive until the join
-    (void)hipEventRecord(ctx->ev_fork, s);
-    (void)hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0);
-    const int rc = backbone_impl(ctx, image, H, W, feat_c, feat_f, a, ctx->side_stream, 2, &bufs);
-    (void)hipEventRecord(ctx->ev_join, ctx->side_stream);
-    forked = true;
-    if (rc != OPP_OK) {
-      (void)hipStreamWaitEvent(s, ctx->ev_join, 0);
-      return rc;
+    // fork: if the dependency cannot be expressed the fine branch runs on the caller's stream (same kernels, no overlap)
+    const bool fork_ok = hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0) == hipSuccess;
+    if (!fork_ok) {
+      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 2, &bufs));
+    } else {
+      const int rc = backbone_impl(ctx, image, H, W, feat_c, feat_f, a, ctx->side_stream, 2, &bufs);
+      if (hipEventRecord(ctx->ev_join, ctx->side_stream) != hipSuccess) {
+        // the join cannot be expressed as an event: wait for the side stream on the host before anything reuses its buffers
+        (void)hipStreamSynchronize(ctx->side_stream);
+        if (rc != OPP_OK) return rc;
+      } else {
+        forked = true;
+        if (rc != OPP_OK) {
+          if (hipStreamWaitEvent(s, ctx->ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(ctx->side_stream);
+          return rc;
+        }
+      }
     }
   } else {
     OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
@@ -1693,7 +1750,7 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
     hipStream_t s;
     bool on;
     ~Join() {
-      if (on) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+      if (on && hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) (void)hipStreamSynchronize(c->side_stream);   // never unsynchronised
     }
   } join{ctx, s, forked};
   a.off = mark;
@@ -1722,6 +1779,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
   if (M <= 0) return OPP_OK;
   OPP_CHECK_ARG(ctx && ctx->packed && feat_f && bank_f && i_ids && j_ids && mkpts_c && expec_f && mkpts_f && ws,
                 "fine: null argument");
+  OPP_CHECK_ARG(ctx->tr_packed || !run_transformer, "fine: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(hc > 0 && Hf % hc == 0, "fine: fine map height %d not a multiple of coarse %d", Hf, hc);
   hipStream_t s = (hipStream_t)stream;
   const int C = ctx->cfg.fine_d_model, Wwin = ctx->cfg.fine_window, WW = Wwin * Wwin;

@@ -528,7 +528,8 @@ int opp_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, size_t x_p
   a.dy_bytes = (unsigned)((size_t)P * ldy * 4);
   a.x_bytes = (unsigned)(x_pixels * ldx * 4);
   const size_t lds = (size_t)2 * kBuf * sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static OppLdsOnce lds_once;
+  opp_lds_opt_in(reinterpret_cast<const void*>(conv_wgrad_kernel), lds, lds_once);
   const int blocks = opp_cdiv(a.splits, 8) * 8 * T;
   {
     OppProfScope prof(OPP_PROF_CONV_WGRAD, stream, 2.0 * (double)P * cout * cin * ks * ks);

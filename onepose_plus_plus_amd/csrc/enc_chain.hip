@@ -350,11 +350,8 @@ int launch_chain(const OppEncChain& a, hipStream_t stream) {
   constexpr int TILE_A = kRows * a_stride_bytes(C);
   constexpr size_t lds = 2 * TILE_A + kRows * (C + 4) * 4 + 1024;
   auto k = enc_chain_kernel<C, APPLY, DEPTH, ABL>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static OppLdsOnce lds_once;            // per device (opp_common.h)
+  opp_lds_opt_in(reinterpret_cast<const void*>(k), lds, lds_once);
   const int tiles = opp_cdiv(a.len0, kRows) + opp_cdiv(a.len1, kRows);
   // algorithmic FLOPs: merge C*C + mlp.0 2C*2C + mlp.2 2C*C per token (+ the apply: C*32 per token)
   OppProfScope prof(OPP_PROF_ENC_CHAIN, stream, 2.0 * (double)(a.len0 + a.len1) * (7.0 * C * C + (APPLY ? 32.0 * C : 0.0)));

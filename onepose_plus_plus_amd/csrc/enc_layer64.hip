@@ -330,11 +330,8 @@ int opp_enc_layer64(const OppEncChain& a, hipStream_t stream) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   OPP_CHECK_ARG(al16(a.X) && al16(a.out) && al16(a.q) && a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && al16(a.g1) && al16(a.b1) &&
                     al16(a.g2) && al16(a.b2) && al16(a.wm) && al16(a.w1) && al16(a.w2), "enc_layer64: operands must be 16-byte aligned");
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(enc_layer64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds64);
-    attr_done = true;
-  }
+  static OppLdsOnce lds_once;            // per device (opp_common.h)
+  opp_lds_opt_in(reinterpret_cast<const void*>(enc_layer64_kernel), kLds64, lds_once);
   const int tiles = opp_cdiv(a.len0, R64) + opp_cdiv(a.len1, R64);
   OppProfScope prof(OPP_PROF_ENC_CHAIN, stream, 2.0 * (double)(a.len0 + a.len1) * (7.0 * C * C + 32.0 * C));
   hipLaunchKernelGGL(enc_layer64_kernel, dim3(tiles), dim3(NT), kLds64, stream, a);

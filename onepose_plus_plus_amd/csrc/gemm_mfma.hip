@@ -163,8 +163,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // rotation of the chunk order (to spread L2 channels) was measured and gave nothing.
   // dense split-K (g.k_splits > 1, plain epilogue only): blockIdx.y walks chunks [k_first, k_first + nk) of K and writes its
   // partial product to C + blockIdx.y * split_stride; opp_splitk_reduce sums the partials in split order
-  const int k_first = (!CONV && g.k_splits > 1) ? (int)blockIdx.y * g.k_chunks_per_split : 0;
-  const int nk = (!CONV && g.k_splits > 1) ? max(0, min(g.k_chunks_per_split, g.K / 32 - k_first)) : g.K / 32;
+  // (conv mode as well: the short, long-K convolutions of the 1/8-resolution stage split K over grid.y so that they fill the chip;
+  // opp_splitk_epilogue sums the partials in split order and applies bias / residual / activation)
+  const int k_first = g.k_splits > 1 ? (int)blockIdx.y * g.k_chunks_per_split : 0;
+  const int nk = g.k_splits > 1 ? max(0, min(g.k_chunks_per_split, g.K / 32 - k_first)) : g.K / 32;
   const int taps = CONV ? g.ksize * g.ksize : 1;
   const int ngrp = CONV ? g.Cin / 32 : nk;            // rotation period: channel groups / chunks
   int cur_i = 0;                                      // chunks issued so far
@@ -185,11 +187,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     delta = (unsigned)((ty * g.Win + tx) * g.Cin + g.tail_grp * 32 - kq_lane * 4) * 4u;
     sh = (unsigned)(31 - tp);
   };
-  auto advance = [&]() {
-    ++cur_i;
-    cur_past = cur_i < nk ? 0u : kOob;
+  // conv: moves the (tap, channel group) cursor one chunk forward
+  auto step_cursor = [&]() {
     if (CONV) {
-      cur_k0 = cur_i * 32;                            // the packed K order is the chunk order
       if (tail_i < 0) {
         ++cur_tap;
         if (++cur_kx == g.ksize) {
@@ -213,11 +213,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       } else {
         tail_lane(tail_i & 1, eff_delta, eff_sh);     // chunks past the end are killed by cur_past
       }
+    }
+  };
+  auto advance = [&]() {
+    ++cur_i;
+    cur_past = cur_i < nk ? 0u : kOob;
+    if (CONV) {
+      cur_k0 = (k_first + cur_i) * 32;                // the packed K order is the chunk order
+      step_cursor();
     } else {
       if (++cur_grp == ngrp) cur_grp = 0;
       cur_k0 = (k_first + cur_grp) * 32;
     }
   };
+  if (CONV && k_first > 0) {                          // split-K slice: walk the cursor to its first chunk (wave-uniform scalar work)
+    for (int t = 0; t < k_first; ++t) step_cursor();
+  }
 
   // global -> registers for the chunk the cursor points at; item i in [0, A_LD + B_LD) is one
   // buffer_load_dwordx4 so that the loads can be issued one at a time between MFMAs.
@@ -950,7 +961,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           for (int e = 0; e < 4; ++e) v[e] *= rm;
         }
       }
-      float* cp = g.C + (size_t)row * g.ldc + col + ((!CONV && g.k_splits > 1) ? (size_t)blockIdx.y * g.split_stride : 0);
+      float* cp = g.C + (size_t)row * g.ldc + col + (g.k_splits > 1 ? (size_t)blockIdx.y * g.split_stride : 0);
       if (vec_ok) {
         *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -967,12 +978,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   }
 }
 
-template <typename K>
-void set_lds_once(K k, size_t lds, bool& done) {
-  if (!done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
+// out = act(sum_s part[s] + bias + R): the split-K slices of a convolution summed in slice order (deterministic), then the epilogue
+// the unsplit kernel fuses (folded-BN bias, same-shape residual, ReLU / LeakyReLU); float4 granularity over [M][ld]
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __restrict__ part, int splits, size_t stride4, size_t n4, int ld4,
+                                                              const float4* __restrict__ bias, const float4* __restrict__ R, int act,
+                                                              float4* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = part[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = part[(size_t)s * stride4 + i];
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
+    if (bias) {
+      const float4 b = bias[i % (size_t)ld4];
+      a.x += b.x;
+      a.y += b.y;
+      a.z += b.z;
+      a.w += b.w;
+    }
+    if (R) {
+      const float4 r = R[i];
+      a.x += r.x;
+      a.y += r.y;
+      a.z += r.z;
+      a.w += r.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (act == OPP_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+    } else if (act == OPP_ACT_LEAKY) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+    }
+    out[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
+}
+
+template <typename K>
+void set_lds_once(K k, size_t lds, OppLdsOnce& once) {   // per device: a process may drive several GPUs
+  opp_lds_opt_in(reinterpret_cast<const void*>(k), lds, once);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH, int PREC>
@@ -991,12 +1039,12 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
     if (g.conv) {
       auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, PREC>;
-      static bool attr_done = false;
+      static OppLdsOnce attr_done;
       set_lds_once(k, lds, attr_done);
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);
+      hipLaunchKernelGGL(k, dim3(tiles, g.k_splits > 1 ? g.k_splits : 1), dim3(NT), lds, stream, g);
     } else {
       auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, false, 0, DEPTH, PREC>;
-      static bool attr_done = false;
+      static OppLdsOnce attr_done;
       set_lds_once(k, lds, attr_done);
       hipLaunchKernelGGL(k, dim3(tiles, g.k_splits > 1 ? g.k_splits : 1), dim3(NT), lds, stream, g);
     }
@@ -1120,11 +1168,42 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     OPP_CHECK_ARG(g.res_mode != OPP_RES_BILINEAR2X, "gemm: bilinear residual needs conv mode");
   }
   if (g.k_splits > 1) {
-    OPP_CHECK_ARG(!g.conv && g.k_chunks_per_split > 0 && (long long)g.k_splits * g.k_chunks_per_split * 32 >= g.K && g.split_stride >= (size_t)g.M * g.ldc,
+    OPP_CHECK_ARG(g.k_chunks_per_split > 0 && (long long)g.k_splits * g.k_chunks_per_split * 32 >= g.K && g.split_stride >= (size_t)g.M * g.ldc,
                   "gemm: bad split-K description (%d splits x %d chunks for K %d)", g.k_splits, g.k_chunks_per_split, g.K);
     OPP_CHECK_ARG(!g.bias && g.res_mode == OPP_RES_NONE && g.act == OPP_ACT_NONE && !g.ln_gamma && !g.stat_rowmax && !g.col_mask &&
                       g.out_mul == 1.f && g.out_div == 1.f, "gemm: split-K partial products take a plain epilogue");
     OPP_CHECK_ARG((size_t)g.k_splits * g.split_stride < (1ull << 31), "gemm: split-K partials too large for 32-bit indexing");
+  }
+  if (g.conv && cfg < 0 && g.prec == OPP_PREC_BF16X3 && g.k_splits <= 1 && g.splitk_ws != nullptr && !g.ln_gamma && !g.stat_rowmax && !g.col_mask &&
+      (g.res_mode == OPP_RES_NONE || (g.res_mode == OPP_RES_DIRECT && g.ldr == g.ldc)) && (g.act == OPP_ACT_NONE || g.act == OPP_ACT_RELU || g.act == OPP_ACT_LEAKY) &&
+      g.out_mul == 1.f && g.out_div == 1.f && g.vec_epilogue && g.n_store == g.ldc) {
+    // few output tiles under a long K (shape-only decision, identical under both tile policies): 4 K slices on the 8-wave 128 x 128 tile
+    constexpr int kSplits = 4;
+    const long long tiles128 = (long long)opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
+    const int nkc = g.K / 32;
+    const size_t need = (size_t)kSplits * g.M * g.ldc;
+    if (tiles128 <= 64 && nkc >= 32 && g.splitk_ws_floats >= need && need < (1ull << 31)) {
+      OppGemm gs = g;
+      gs.C = g.splitk_ws;
+      gs.k_splits = kSplits;
+      gs.k_chunks_per_split = opp_cdiv(nkc, kSplits);
+      gs.split_stride = (size_t)g.M * g.ldc;
+      gs.bias = nullptr;
+      gs.res_mode = OPP_RES_NONE;
+      gs.R = nullptr;
+      gs.act = OPP_ACT_NONE;
+      gs.splitk_ws = nullptr;
+      OPP_TRY(opp_gemm_launch_cfg(gs, 25, stream));
+      const size_t n4 = (size_t)g.M * g.ldc / 4;
+      const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+      // algorithmic bytes of the reduction: the partial slices read, the residual read, the output written
+      OppProfScope prof_epi(OPP_PROF_SPLITK_EPILOGUE, stream, (double)(kSplits + 1 + (g.res_mode == OPP_RES_DIRECT ? 1 : 0)) * (double)g.M * g.ldc * 4.0);
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(g.splitk_ws), kSplits, n4, n4, g.ldc / 4,
+                         reinterpret_cast<const float4*>(g.bias), g.res_mode == OPP_RES_DIRECT ? reinterpret_cast<const float4*>(g.R) : nullptr, g.act,
+                         reinterpret_cast<float4*>(g.C));
+      OPP_CHECK_LAUNCH("splitk_epilogue_kernel");
+      return OPP_OK;
+    }
   }
   const bool auto_cfg = cfg < 0;
   if (cfg < 0) {
@@ -1209,7 +1288,8 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
                   "gemm: fused LayerNorm needs a 256- or 128-column output, no bias/activation/residual mode, aligned operands");
   }
   // live timing of this symbol when armed (bench.py roofline leg)
-  OppProfScope prof_scope(opp_prof_gemm_symbol(cfg, g.conv ? 1 : (g.stat_rowmax ? 2 : 0)), stream,
+  // (the K slices of a split convolution have their own symbol: they are a different kernel shape than the same tile unsplit)
+  OppProfScope prof_scope(g.conv && g.k_splits > 1 ? (int)OPP_PROF_CONV_SPLITK : opp_prof_gemm_symbol(cfg, g.conv ? 1 : (g.stat_rowmax ? 2 : 0)), stream,
                           g.alg_flops > 0.0 ? g.alg_flops : 2.0 * (double)g.M * (double)g.N * (double)g.K);
   int rc;
   switch (cfg) {

@@ -550,11 +550,8 @@ template <int MODE>
 int launch_ss(const OppGemmSS& g, hipStream_t stream, int symbol) {
   constexpr size_t lds = (size_t)NS * SLOT;
   auto k = gemm_ss_kernel<MODE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  static OppLdsOnce lds_once;            // per device (opp_common.h)
+  opp_lds_opt_in(reinterpret_cast<const void*>(k), lds, lds_once);
   const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.N, BN);
   OppProfScope prof(symbol, stream, 2.0 * (double)g.M * (double)g.N * (double)g.K);
   hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), lds, stream, g);

@@ -37,6 +37,20 @@ void opp_set_error(const char* fmt, ...);
     if (rc__ != OPP_OK) return rc__; \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize (kernels with more than 64 KB of dynamic LDS) is a PER-DEVICE attribute: one flag per
+// (kernel instantiation, device), so that a process driving several GPUs opts in on each of them
+struct OppLdsOnce {
+  bool done[32] = {};
+};
+inline void opp_lds_opt_in(const void* kernel, size_t lds_bytes, OppLdsOnce& once) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool tracked = dev >= 0 && dev < 32;
+  if (tracked && once.done[dev]) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (tracked) once.done[dev] = true;
+}
+
 static inline int opp_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t opp_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
@@ -138,6 +152,12 @@ struct OppGemm {
   int k_splits = 1;
   int k_chunks_per_split = 0;
   size_t split_stride = 0;
+  // conv mode, automatic tile choice: scratch for split-K partial products (>= 4 * M * ldc floats).  When given, a convolution whose
+  // output is at most 64 tiles of 128 x 128 under a K of >= 32 chunks (the 3x3 convolutions of the 1/8-resolution stage at B = 1:
+  // 4096 pixels x 256 channels x K = 2304) runs as 4 K slices on 8-wave 128 x 128 tiles -- 256 workgroups instead of 64 .. 256
+  // four-wave ones -- and a fixed-order reduction applies bias / residual / activation.  The decision depends on the shape only.
+  float* splitk_ws = nullptr;
+  size_t splitk_ws_floats = 0;
 };
 
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // dx = rstd * (g gamma - mean(g gamma) - xhat mean(g gamma xhat)); block partials of dgamma = sum g xhat, dbeta = sum g
 // 4 waves x kLnRowsPerWave rows per block; part [blocks][2][C]
-constexpr int kLnRowsPerWave = 16;
+constexpr int kLnRowsPerWave = 32;
 template <int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd, int rows,
@@ -103,14 +103,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
   }
 }
 
-// out[k][c] = sum over the blocks (ascending, fp64) of part[b][k][c]; k = 0 dgamma, 1 dbeta
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * C) return;
-  const int k = e / C, c = e - k * C;
+// out[k][c] = sum over the blocks of part[b][k][c] (k = 0 dgamma, 1 dbeta): 16 columns x 16 slices per workgroup, slice s adds
+// blocks s, s + 16, ... in ascending order, the 16 slice sums are then added in slice order (fixed order = deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+  __shared__ double red[16][16];
+  const int cx = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + cx;                 // column of the [2 C] row (k, c)
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)part[((size_t)b * 2 + k) * C + c];
-  (k == 0 ? dgamma : dbeta)[c] = (float)s;
+  if (e < 2 * C) {
+    const int k = e / C, c = e - k * C;
+    for (int b = sl; b < blocks; b += 16) s += (double)part[((size_t)b * 2 + k) * C + c];
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl != 0 || e >= 2 * C) return;
+  s = 0.0;
+  for (int k = 0; k < 16; ++k) s += red[k][cx];
+  (e < C ? dgamma : dbeta)[e < C ? e : e - C] = (float)s;
 }
 
 // ---- log-sum-exp of the rows and columns of S [B][N][L] ------------------------------------------------------------------
@@ -257,7 +267,7 @@ int opp_ln_backward(const float* g, const float* x, const float* gamma, const fl
     opp_set_error("layer_norm_train: C must be 64, 128 or 256 (got %d)", C);
     return OPP_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(opp_cdiv(2 * C, 256)), dim3(256), 0, stream, part, blocks, C, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(opp_cdiv(2 * C, 16)), dim3(256), 0, stream, part, blocks, C, dgamma, dbeta);
   OPP_CHECK_LAUNCH("ln_bwd kernels");
   return OPP_OK;
 }

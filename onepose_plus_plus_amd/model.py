@@ -344,9 +344,12 @@ class OnePosePlus_model(nn.Module):
         c.fpn_overlap = 1 if getattr(self, "fpn_overlap", True) else 0
         return c
 
-    def _ensure_ready(self, device):
+    def _ensure_ready(self, device, scope=0):
+        """scope 1 (training graph): only the backbone is packed -- the other stages read the parameters themselves"""
         lib = _lib.load()
         rt = self._rt
+        if rt.get("scope", 0) != scope:
+            rt["dirty"] = True
         if rt["ctx"] is None:
             ctx = ctypes.c_void_p()
             ccfg = self._c_config()
@@ -373,7 +376,9 @@ class OnePosePlus_model(nn.Module):
             nbytes = lib.opp_packed_weights_bytes(rt["ctx"])
             blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
             stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(lib.opp_set_pack_scope(rt["ctx"], scope), "opp_set_pack_scope")
             _lib.check(lib.opp_pack_weights(rt["ctx"], ptrs, n, blob.data_ptr(), nbytes, stream), "opp_pack_weights")
+            rt["scope"] = scope
             rt["packed"] = blob
             rt["dirty"] = False
             rt["keep"] = keep
@@ -588,7 +593,7 @@ class OnePosePlus_model(nn.Module):
             from . import train_autograd as TA
         self._rt["dirty"] = True                      # parameters change between training steps: always repack
         self._rt["obj"] = None
-        lib, ctx = self._ensure_ready(device)
+        lib, ctx = self._ensure_ready(device, scope=1 if graph else 0)
         _lib.check(lib.opp_set_status_flag(ctx, None), "opp_set_status_flag")   # no sticky pointer from an eval forward
         stream = torch.cuda.current_stream(device).cuda_stream
         data.update({"bs": B, "q_hw_i": img.shape[2:], "q_hw_c": torch.Size([hc, wc]), "q_hw_f": torch.Size([hf, wf])})
@@ -690,9 +695,11 @@ class OnePosePlus_model(nn.Module):
         scale_total = scale_c * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_c   # :222-225
         mk_query = torch.stack([j_ids % wc, j_ids // wc], dim=1) * scale_total
         mk_3d = kpts[b_ids, i_ids]
-        keep = mconf != 0
+        # `mconf != 0` of the reference (:226-233) selects exactly the predicted matches, which come first in the padded list
+        # (a predicted confidence is > thr >= 0, a padded one is 0): their count is known on the host -> slices, no device sync
+        n_keep = int(pred_idx.numel()) if tcfg["train_padding"] else int(b_ids.numel())
         data.update({"conf_matrix": conf, "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0,
-                     "m_bids": b_ids[keep], "mkpts_3d_db": mk_3d[keep], "mkpts_query_c": mk_query[keep], "mconf": mconf[keep]})
+                     "m_bids": b_ids[:n_keep], "mkpts_3d_db": mk_3d[:n_keep], "mkpts_query_c": mk_query[:n_keep], "mconf": mconf[:n_keep]})
         if not cfg["fine_matching"]["enable"]:
             data["mkpts_query_f"] = data["mkpts_query_c"]
             return
@@ -705,8 +712,7 @@ class OnePosePlus_model(nn.Module):
             expec = TA.fine_level_graph(self, params, feat_f, bank_f, b_ids, i_ids, j_ids, B, hf, wf, hc, wc)
             with torch.no_grad():                                                         # build_mkpts, fine_matching.py:96-110
                 qs = scale_f * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_f
-                n_keep = int(keep.sum().item())
-                mk_f = mk_query[keep] + (expec[:, :2].detach() * (data["W"] // 2) * qs)[:n_keep]
+                mk_f = mk_query[:n_keep] + (expec[:, :2].detach() * (data["W"] // 2) * qs)[:n_keep]
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             return
         expec = torch.empty((Mp, 3), dtype=torch.float32, device=device)
@@ -729,7 +735,7 @@ class OnePosePlus_model(nn.Module):
             mk_f[sel] = mf_b           # (the shared workspace is reused by the next sample in stream order)
         # mkpts_query_f = mkpts_query_c + (offsets)[:len(mconf)] (fine_matching.py:104-105): the predicted matches
         # come first in the padded list, and they are the ones with mconf != 0
-        data.update({"expec_f": expec, "mkpts_query_f": mk_f[:int(keep.sum().item())]})
+        data.update({"expec_f": expec, "mkpts_query_f": mk_f[:n_keep]})
 
     def _forward_single(self, data, use_token_cache=True, sample=None):
         """One sample (B = 1) through the fused coarse call + the fine call.  `sample` = (query mask [L] floats or

@@ -381,7 +381,7 @@ class HipBackbone(torch.autograd.Function):
     def forward(ctx, model, img, table_idx, *params):
         from . import _lib
         dev = img.device
-        lib, c = model._ensure_ready(dev)
+        lib, c = model._ensure_ready(dev, scope=1)
         model._ensure_train_packed(lib, c, dev)
         cfg = model.config
         B, H, W = int(img.shape[0]), int(img.shape[2]), int(img.shape[3])

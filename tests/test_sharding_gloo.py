@@ -144,3 +144,93 @@ def test_gradient_averager_world2():
         assert n == 144 and numel * 4 > 40e6                       # the whole model in one buffer
         assert attached and own_ok and mean_ok and zero_ok and refused
     assert res[0][-1] == res[1][-1]                                 # same parameters on both ranks after the step
+
+
+# ---- DistributedDataParallel around a module shaped like OnePosePlus_model in train() mode -----------------------------------
+class _ScaleFn(torch.autograd.Function):
+    """stand-in for the HIP nodes of train_autograd.py: a custom autograd.Function that takes PARAMETERS as inputs and returns
+    their gradients from its own backward (the reducer hooks of DDP must fire on them like on any leaf)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return g @ w, g.t() @ x, g.sum(0)
+
+
+class _DictModule(torch.nn.Module):
+    """same calling convention as OnePosePlus_model.forward: results are written into the `data` dict, which is also returned"""
+
+    def __init__(self):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(8, 6))
+        self.b1 = torch.nn.Parameter(torch.zeros(8))
+        self.w2 = torch.nn.Parameter(torch.randn(3, 8))
+        self.b2 = torch.nn.Parameter(torch.zeros(3))
+
+    def forward(self, data):
+        h = torch.relu(_ScaleFn.apply(data["x"], self.w1, self.b1))
+        data["out"] = _ScaleFn.apply(h, self.w2, self.b2)
+        return data
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7 + rank)                       # ranks start from DIFFERENT parameters: DDP must broadcast rank 0's
+        model = _DictModule()
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        g = torch.Generator().manual_seed(40 + rank)
+        d = {"x": torch.randn(5, 6, generator=g), "meta": "kept"}
+        out = ddp(d)                                      # DDP rebuilds dict inputs: the RETURNED dict carries the results
+        returned_has_out = "out" in out
+        caller_dict_has_out = "out" in d                  # documents why callers must use the return value
+        out["out"].square().sum().backward()
+        flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+        # the mean of the two ranks' own gradients, from an un-wrapped copy of the synchronised parameters
+        ref = _DictModule()
+        ref.load_state_dict(model.state_dict())
+        o = ref({"x": d["x"]})
+        o["out"].square().sum().backward()
+        own = torch.cat([p.grad.flatten() for p in ref.parameters()])
+        owns = [torch.empty_like(own) for _ in range(world)]
+        dist.all_gather(owns, own)
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        psame = [torch.empty(sum(p.numel() for p in model.parameters())) for _ in range(world)]
+        dist.all_gather(psame, torch.cat([p.detach().flatten() for p in model.parameters()]))
+        q.put((rank, returned_has_out, caller_dict_has_out, bool(torch.equal(gathered[0], gathered[1])),
+               bool(torch.allclose(flat, sum(owns) / world, rtol=1e-6, atol=1e-8)), bool(torch.equal(psame[0], psame[1])),
+               not torch.equal(owns[0], owns[1])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_around_a_dict_mutating_module_with_custom_autograd_functions():
+    """The two DDP behaviours the training path depends on (tests/test_multi_gpu.py runs the real module over RCCL when two GPUs
+    are visible): (1) DistributedDataParallel copies dict inputs, so results written into `data` reach the caller only through the
+    RETURN value -- OnePosePlus_model.forward returns `data` for that reason; (2) gradients produced by custom autograd.Functions
+    that take parameters as inputs are averaged by DDP's reducer like any others."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        returned_has_out, caller_has_out, same, is_mean, params_same, ranks_differ = res[r]
+        assert returned_has_out and same and is_mean and params_same and ranks_differ, (r, res[r])

@@ -64,9 +64,9 @@ def test_conv2d_backward_vs_autograd(B, cin, cout, ks, stride, H, W, prec):
     _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), gx.data_ptr(),
                                             gw.data_ptr(), prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
     torch.cuda.synchronize()
-    assert _rel(_from_nhwc(gx, cin), xd.grad) < 2e-6, "grad_x"
+    assert _rel(_from_nhwc(gx, cin), xd.grad) < 5e-6, "grad_x"
     assert (gx[..., cin:] == 0).all(), "padded channels of grad_x must be exact zeros"
-    assert _rel(gw.cpu(), wd.grad) < 2e-6, "grad_w"
+    assert _rel(gw.cpu(), wd.grad) < 5e-6, "grad_w"
     # deterministic: fixed-order split reduction
     gw2 = torch.empty_like(gw)
     _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), None,
