@@ -88,11 +88,15 @@ MFMA_SYMBOLS = [
     (1012, "gemm_ss_kernel<3>", "coarse score GEMM on operands pre-split once, LDS-DMA staged, + dual-softmax statistics + score matrix"),
     (1010, "gemm_ss_kernel<1>", "coarse score GEMM sweep 1 (statistics only; two-sweep matcher)"),
     (1011, "gemm_ss_kernel<2>", "coarse score GEMM sweep 2 (confidences written once; two-sweep matcher)"),
+    (1014, "opp_gemm_kernel<128, 128, 4, 2, true> x 4 K slices", "3x3 convolutions of the 1/8-resolution stage (4096 pixels, K = 1792 .. 2304) as "
+                                                                  "four K slices on 8-wave tiles: 256 workgroups instead of 64 four-wave ones"),
 ]
+EMPTY_KERNEL_US = 1.5        # duration of opp_empty_kernel in the rocprofv3 kernel trace (profiles/r04_kernel_stats_*.csv)
 HBM_SYMBOLS = [
     (1000, "linattn_kv_mfma_kernel", "linear-attention gather: sum_s phi(K_s)^T V_s (K, V read once + chunk partials written)"),
     (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
     (1002, "conf_reg_kernel", "dual-softmax product over the N x L score matrix (read + written once)"),
+    (1015, "splitk_epilogue_kernel", "K slices of a split convolution summed in slice order + bias / residual / activation"),
 ]
 
 
@@ -140,7 +144,89 @@ def main():
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.call(cmd, env=env))
+    if os.environ.get("OPP_BENCH_DRY_RUN") == "1":
+        return run_dry(args)
     run(args)
+
+
+def timed_region(run_steps, n, barrier, sync):
+    """The contract's timed region: barrier + device sync, EXACTLY n forwards, device sync, barrier.
+    -> (last result, this rank's own time before the closing barrier, time including it)"""
+    barrier()
+    t0 = time.perf_counter()
+    last = run_steps(n)
+    sync()
+    own_elapsed = time.perf_counter() - t0      # this rank alone (before the closing barrier): per-rank rate
+    barrier()
+    return last, own_elapsed, time.perf_counter() - t0
+
+
+def gather_ranks(dist, torch, dev, elapsed, info):
+    """-> (MAX of `elapsed` over the ranks, every rank's `info` record in rank order, ranks seen); dist = None: single process"""
+    if dist is None:
+        return elapsed, [info], 1
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    devs = [None] * dist.get_world_size()
+    dist.all_gather_object(devs, info)
+    return float(t.item()), devs, dist.get_world_size()
+
+
+def per_rank_summary(devs):
+    per_rank = [d["images_per_s"] for d in devs]
+    return {"min": min(per_rank), "max": max(per_rank), "sum": round(sum(per_rank), 2)}
+
+
+def run_dry(args):
+    """OPP_BENCH_DRY_RUN=1 (tests/test_bench_dry_cpu.py): the multi-rank skeleton of this file -- launcher, RANK / WORLD_SIZE
+    handling, weight broadcast, barriers, max-over-ranks timing, per-rank gather, the one JSON line of rank 0 -- over gloo on
+    CPU tensors with a stand-in for the forward (a sleep whose length depends on the rank), so that the code the first
+    multi-GPU lease will execute has run somewhere.  Not a measurement: the line says so."""
+    import torch
+    import torch.distributed as dist
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd.sharding import broadcast_weights
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dev = torch.device("cpu")
+    d = None
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        d = dist
+    cfg = default_config(thr=args.thr, fine=args.fine)
+    model = OnePosePlus_model(cfg).eval()
+    sd = make_state_dict(cfg, 0) if rank == 0 else None
+    if d is not None:
+        broadcast_weights(model, sd, src=0)
+    else:
+        model.load_state_dict(sd, strict=True)
+    checksum = float(sum(float(v.double().sum()) for v in model.state_dict().values() if v.is_floating_point()))
+    ips = max(1, args.images_per_step)
+
+    def run_steps(n):
+        time.sleep(n * 0.001 * (1.0 + 0.5 * rank))          # rank r is 1 + r / 2 times slower: max-over-ranks must show
+        return {"mconf": torch.zeros(0)}
+
+    def barrier():
+        if d is not None:
+            d.barrier()
+    run_steps(max(args.warmup, 1) * ips)
+    last, own, elapsed = timed_region(run_steps, args.steps * ips, barrier, lambda: None)
+    elapsed, devs, seen = gather_ranks(d, torch, dev, elapsed, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+                                                              "images_per_s": round(args.steps * ips / own, 2), "weights_checksum": checksum})
+    if rank == 0:
+        total = args.steps * ips * world
+        print(json.dumps({"metric": "DRY RUN (no GPU work): multi-rank skeleton of bench.py over gloo", "value": round(total / elapsed, 3),
+                          "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "data": "none", "config": {"workload": "dry run", "images_per_step": ips, "per_rank_images_per_s": per_rank_summary(devs),
+                                                     "n_ranks_seen": seen, "rank_devices": devs}}), flush=True)
+    if d is not None:
+        d.destroy_process_group()
 
 
 def pin_to_gpu_numa_node(torch, dev):
@@ -293,31 +379,13 @@ def run(args):
     lib = _lib.load()
     prof = (not args.no_roofline) and rank == 0 and world == 1
 
-    barrier()
-    t0 = time.perf_counter()
-    last = run_steps(args.steps * ips)
-    torch.cuda.synchronize(dev)
-    own_elapsed = time.perf_counter() - t0      # this rank alone (before the closing barrier): per-rank rate below
-    barrier()
-    elapsed = time.perf_counter() - t0
+    last, own_elapsed, elapsed = timed_region(run_steps, args.steps * ips, barrier, lambda: torch.cuda.synchronize(dev))
     matches_last = int(last["mconf"].numel())
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        devs = [None] * world
-        props = torch.cuda.get_device_properties(dev)
-        dist.all_gather_object(devs, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
-                                      "name": props.name, "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
-                                      "images_per_s": round(args.steps * ips / own_elapsed, 2), "host_affinity": affinity})
-        n_ranks_seen = dist.get_world_size()
-    else:
-        props = torch.cuda.get_device_properties(dev)
-        devs = [{"rank": 0, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
-                 "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
-                 "images_per_s": round(args.steps * ips / own_elapsed, 2), "host_affinity": affinity}]
-        n_ranks_seen = 1
+    props = torch.cuda.get_device_properties(dev)
+    elapsed, devs, n_ranks_seen = gather_ranks(dist, torch, dev, elapsed, {
+        "rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
+        "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+        "images_per_s": round(args.steps * ips / own_elapsed, 2), "host_affinity": affinity})
 
     roof = None
     if prof:
@@ -344,7 +412,6 @@ def run(args):
 
     if rank == 0:
         total = args.steps * ips * world
-        per_rank = [d["images_per_s"] for d in devs]
         if roof is not None and legs:      # compact copies of the secondary legs inside `roofline` (driver-side parsers keep it whole)
             roof["legs"] = compact_legs(legs)
         flops_img = 2 * (126.726e9 + 6 * (4096 + args.n_points) * 671744 + args.n_points * 4096 * 256)
@@ -365,7 +432,7 @@ def run(args):
                                    % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", ips, n_streams,
                                       args.thr, matches_last),
                        "images_per_step": ips, "streams_per_gpu": n_streams,
-                       "per_rank_images_per_s": {"min": min(per_rank), "max": max(per_rank), "sum": round(sum(per_rank), 2)}, "gemm_precision": precision, "tile_policy": policy, "fpn_overlap": bool(overlap),
+                       "per_rank_images_per_s": per_rank_summary(devs), "gemm_precision": precision, "tile_policy": policy, "fpn_overlap": bool(overlap),
                        "matches_last_step": matches_last, "object_token_cache": True,
                        "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
                        "model_gflop_per_image": round(flops_img / 1e9, 1),
@@ -393,6 +460,9 @@ def compact_legs(legs):
     t = legs.get("coarse_only_without_unused_fine_map_leg")
     if t:
         out["coarse_only_without_unused_fine_map_images_per_s"] = t.get("value")
+    t = legs.get("object_token_cache_off_leg")
+    if t:
+        out["object_token_cache_off_images_per_s"] = t.get("value")
     f = legs.get("fine_leg") or {}
     if "ms_per_forward" in f:
         out["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak")}
@@ -400,7 +470,7 @@ def compact_legs(legs):
         out["fine"] = f
     tr = legs.get("train_leg") or {}
     if "step_ms" in tr:
-        out["train"] = {k: tr.get(k) for k in ("forward_ms", "step_ms", "backward_ms_in_opp_kernels", "step_samples_per_s")}
+        out["train"] = {k: tr.get(k) for k in ("forward_ms", "step_ms", "backward_ms_in_opp_kernels", "backward_kernel_split", "step_samples_per_s")}
     elif tr:
         out["train"] = tr
     return out
@@ -445,6 +515,9 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
         with open(tpath) as f:
             traffic = json.load(f)
     meas = []
+    ov = ctypes.c_double()
+    _lib.check(lib.opp_profile_event_overhead(200, ctypes.byref(ov), torch.cuda.current_stream(dev).cuda_stream), "profile_event_overhead")
+    event_pair_us = ov.value          # what an (event, empty kernel, event) triple reads: the floor of every measurement below
     for cfg_id, kind, tile, what in GEMM_SYMBOLS:
         spid = 0 if (kind == 2 and precision == "fp16x2") else pid      # fp16x2: the score GEMM stays fp32
         ms, fl, n = prof_run(lib, _lib, torch, dev, step, cfg_id, kind, nsteps)
@@ -481,6 +554,13 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
                      "us_per_forward": round(ms * 1e3 / nsteps, 1), "alg_mbytes_per_launch": round(by / n / 1e6, 3)})
     if not meas:
         return None
+    # launches shorter than 15 us: the event pair around them reads `event_pair_us` even for an EMPTY kernel (whose own duration in
+    # the rocprofv3 kernel trace is kEmptyKernelUs), so the part of a reading that is not the kernel is event_pair_us - kEmptyKernelUs
+    for m in meas:
+        if m["avg_launch_us"] < 15.0:
+            t = max(m["avg_launch_us"] - max(event_pair_us - EMPTY_KERNEL_US, 0.0), 0.25 * m["avg_launch_us"])
+            m["avg_launch_us_event_corrected"] = round(t, 2)
+            m["frac_event_corrected"] = round(m["frac"] * m["avg_launch_us"] / t, 4)
     meas.sort(key=lambda m: -m["us_per_forward"])
     # the line stays short enough for log tails: strings every entry shares are kept once, on the dominant kernel's entry
     src = None
@@ -494,6 +574,9 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     if src:
         roof["traffic_source"] = src
     roof["other_kernels"] = meas[1:]
+    roof["event_pair_us"] = round(event_pair_us, 2)
+    roof["event_correction"] = ("symbols under 15 us per launch also carry frac_event_corrected: time minus (event_pair_us - %.1f us), the reading "
+                                "of an empty kernel between two events minus its duration in the kernel trace" % EMPTY_KERNEL_US)
     return roof
 
 
@@ -558,6 +641,24 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
                     "match indices / confidences identical"}
         for m in models:
             m.set_skip_unused_fine_map(False)
+    # the headline keeps the image-independent 3D-point tokens of the resident object (keypoint MLP + bank transpose, ~2 % of a
+    # forward) cached; this leg re-encodes them for every image, i.e. does exactly the reference's per-image work
+    for m in models:
+        m.cache_object_tokens = False
+        m.invalidate_object_cache()
+    for k in range(n_streams):
+        step(0, k)
+    torch.cuda.synchronize(dev)
+    run_steps(2 * n_streams)
+    n = min(args.steps * max(1, args.images_per_step), 320)
+    t1 = time.perf_counter()
+    run_steps(n)
+    torch.cuda.synchronize(dev)
+    legs["object_token_cache_off_leg"] = {"value": round(n / (time.perf_counter() - t1), 3), "unit": "images/s", "steps": n,
+                                          "note": "cache_object_tokens = False: keypoint encoding + bank transpose per image like "
+                                                  "OnePosePlusModel.py:144-156"}
+    for m in models:
+        m.cache_object_tokens = True
     try:
         legs["fine_leg"] = fine_leg(torch, dev, precision, lib, _lib)
     except Exception as e:      # the fixture is optional for the headline

@@ -90,6 +90,9 @@ typedef struct opp_ctx opp_ctx;
 
 const char* opp_last_error(void);
 int opp_version(void);
+/* sha256 (hex) of the sources this binary was built from (every file of csrc/ + this header), baked in by the build;
+ * the Python binding compares it with the sources next to the library and refuses a stale binary. */
+const char* opp_source_hash(void);
 
 /* ---- model handle + weights -------------------------------------------------------------
  * Replaces: OnePosePlus_model.__init__ + load_state_dict (OnePosePlusModel.py:26-94,
@@ -422,6 +425,10 @@ int opp_debug_timestamps(void* buf);
  * opp_profile_stop synchronises and returns the summed time, the summed ALGORITHMIC work (FLOPs with unpadded
  * channel counts for GEMMs, bytes for the 1000+ symbols) and the number of launches measured. */
 int opp_profile_start(int tile_cfg, int kind, int capacity_launches);
+/* What the event pair itself adds to a short launch: an empty kernel timed exactly like an armed symbol (event before, event
+ * after, all pairs enqueued back to back, one synchronisation at the end); *mean_us = mean elapsed time of `launches` pairs.
+ * bench.py reports it beside the sub-15-us symbols and corrects their roofline fractions by it. */
+int opp_profile_event_overhead(int launches, double* mean_us, void* stream);
 int opp_profile_stop(double* total_ms, double* total_work, int* launches);
 
 #ifdef __cplusplus

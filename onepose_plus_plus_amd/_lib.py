@@ -45,6 +45,8 @@ class OppConfig(Structure):
 SIGNATURES = {
     "opp_last_error": (c_char_p, []),
     "opp_version": (c_int, []),
+    "opp_source_hash": (c_char_p, []),
+    "opp_profile_event_overhead": (c_int, [c_int, POINTER(ctypes.c_double), c_void_p]),
     "opp_create": (c_int, [POINTER(OppConfig), POINTER(c_void_p)]),
     "opp_destroy": (None, [c_void_p]),
     "opp_set_status_flag": (c_int, [c_void_p, c_void_p]),
@@ -162,6 +164,15 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # a binary built from other sources than the ones next to it (the GPU box runs the prebuilt .so that travels with the
+    # snapshot) is refused: the library carries the sha256 of its sources (csrc/version.hip, build.py `source_hash`)
+    from .build import source_hash
+    want = source_hash()
+    got = lib.opp_source_hash()
+    got = got.decode() if got else "unknown"
+    if want is not None and got != want and os.environ.get("OPP_ALLOW_STALE_LIB", "0") != "1":
+        raise OppError("%s was built from other sources than the ones in %s (library %s..., sources %s...): rebuild it with "
+                       "`python -m onepose_plus_plus_amd.build`" % (LIB_PATH, os.path.join(_HERE, "csrc"), got[:12], want[:12]))
     _lib = lib
     return lib
 

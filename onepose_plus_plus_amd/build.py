@@ -6,8 +6,11 @@
 environment knobs used by tools/; never loaded by the product path -- point OPP_HIP_LIB at it explicitly).
 
 hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the
-resulting .so travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+resulting .so travels to the GPU box with the repository snapshot (git-ignored, not gpurun-ignored).  The library carries the
+sha256 of the sources it was built from (`opp_source_hash()`, csrc/version.hip); `_lib.load()` compares it with the sources next
+to it and refuses a stale binary.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -17,7 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_build")
 LIB = os.path.join(HERE, "libopp_hip.so")
-SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "stem_direct.hip", "attention.hip", "backbone.hip", "kpt.hip", "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "bn_train.hip", "bankbuild.hip", "loss.hip", "linear_bwd.hip", "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "api.hip"]
+SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "stem_direct.hip", "attention.hip", "backbone.hip", "kpt.hip",
+           "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "bn_train.hip", "bankbuild.hip", "loss.hip", "linear_bwd.hip",
+           "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "version.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -29,6 +34,20 @@ def _hipcc():
     return "hipcc"
 
 
+def source_hash():
+    """sha256 over the names and contents of every source / header of the library (None if the sources are not there)"""
+    h = hashlib.sha256()
+    for rel in sorted(SOURCES + HEADERS):
+        path = os.path.join(CSRC, rel)
+        if not os.path.exists(path):
+            return None
+        h.update(os.path.basename(rel).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -37,7 +56,6 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True, tuning=False):
-    global OBJ, LIB
     obj_dir = OBJ + ("_tuning" if tuning else "")
     lib_path = LIB.replace(".so", "_tuning.so") if tuning else LIB
     flags = FLAGS + (["-DOPP_TUNING"] if tuning else [])
@@ -48,22 +66,31 @@ def _build(force, verbose, OBJ, LIB, FLAGS):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    digest = source_hash()
+    stamp = os.path.join(OBJ, "src_hash.txt")
+    old = open(stamp).read().strip() if os.path.exists(stamp) else ""
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        extra = []
+        if src == "version.hip":
+            extra = ['-DOPP_SRC_HASH="%s"' % digest]
+            if old != digest:                      # any source changed: the hash baked into this object changes with it
+                jobs.append((s, o, extra))
+                continue
         if force or _stale(o, [s] + hdrs):
-            jobs.append((s, o))
+            jobs.append((s, o, extra))
 
     def compile_one(job):
-        s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        s, o, extra = job
+        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
-            for (s, o), r in ex.map(compile_one, jobs):
+            for (s, o, _), r in ex.map(compile_one, jobs):
                 if verbose and r.stderr.strip():
                     sys.stderr.write(r.stderr)
                 if r.returncode != 0:
@@ -74,6 +101,8 @@ def _build(force, verbose, OBJ, LIB, FLAGS):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr)
+    with open(stamp, "w") as f:
+        f.write(digest or "")
     return LIB
 
 

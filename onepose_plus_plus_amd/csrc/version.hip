@@ -1,0 +1,53 @@
+// Identity of the sources this library was built from: sha256 over every file of csrc/ and include/opp_hip.h, passed in by
+// onepose_plus_plus_amd/build.py (-DOPP_SRC_HASH).  onepose_plus_plus_amd/_lib.py recomputes it from the sources next to the
+// .so and refuses a stale binary (the GPU box runs the prebuilt library that travels with the repository snapshot).
+#include "opp_common.h"
+
+#ifndef OPP_SRC_HASH
+#define OPP_SRC_HASH "unknown"
+#endif
+
+extern "C" const char* opp_source_hash(void) { return OPP_SRC_HASH; }
+
+// A kernel that does nothing: opp_profile_event_overhead times it exactly like every armed symbol (an event before, an event
+// after, on the launch stream), which measures what the event pair itself adds to a short launch.
+namespace {
+__global__ void opp_empty_kernel() {}
+}  // namespace
+
+extern "C" int opp_profile_event_overhead(int launches, double* mean_us, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OPP_CHECK_ARG(launches > 0 && launches <= 4096 && mean_us, "profile_event_overhead: bad argument");
+  // like the armed symbols of a forward: all pairs enqueued back to back on a busy stream, one synchronisation at the end
+  const int n = launches + 8;          // the first launches warm the code object up and are not counted
+  hipEvent_t* ev = new hipEvent_t[2 * n];
+  int made = 0;
+  for (; made < 2 * n; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) break;
+  int rc = OPP_OK;
+  if (made < 2 * n) {
+    opp_set_error("profile_event_overhead: hipEventCreate failed");
+    rc = OPP_ERR_LAUNCH;
+  } else {
+    for (int i = 0; i < n; ++i) {
+      (void)hipEventRecord(ev[2 * i], stream);
+      hipLaunchKernelGGL(opp_empty_kernel, dim3(1), dim3(64), 0, stream);
+      (void)hipEventRecord(ev[2 * i + 1], stream);
+    }
+    if (hipEventSynchronize(ev[2 * n - 1]) != hipSuccess) {
+      opp_set_error("profile_event_overhead: hipEventSynchronize failed");
+      rc = OPP_ERR_LAUNCH;
+    } else {
+      double total = 0.0;
+      for (int i = 8; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        total += ms;
+      }
+      *mean_us = total * 1e3 / launches;
+    }
+  }
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}

@@ -119,3 +119,17 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "1792" and out[1] == "1152" and int(out[2]) > 0
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """The library carries the sha256 of the sources it was built from (csrc/version.hip); `_lib.load()` recomputes it from the
+    sources next to the .so and refuses a binary built from anything else -- the GPU box runs the prebuilt .so of the snapshot."""
+    from onepose_plus_plus_amd import _lib, build
+    lib = _lib.load()
+    assert lib.opp_source_hash().decode() == build.source_hash() and len(build.source_hash()) == 64
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 64)          # "the sources changed after the build"
+    with pytest.raises(_lib.OppError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.setenv("OPP_ALLOW_STALE_LIB", "1")                         # explicit override for tooling
+    assert _lib.load() is not None

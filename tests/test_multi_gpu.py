@@ -134,7 +134,7 @@ def _nccl_train_worker(rank, world, port, q, mode):
         else:
             wrapped = model
             avg = GradientAverager(model)
-        wrapped(d)
+        d = wrapped(d)          # DDP copies dict inputs: the results come back in the RETURNED dict (forward returns `data`)
         fine_supervision(d, hparams)
         loss_mod(d)
         d["loss"].backward()
