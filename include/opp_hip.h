@@ -293,12 +293,13 @@ int opp_backbone_backward(opp_ctx* ctx, const float* image, int B, int H, int W,
 
 /* Backward of one nn.Conv2d (bias-free, kernel 1 or 3, padding k/2, stride 1 or 2; backbone/resnet.py:10-18) over NHWC tensors
  * whose channel counts are padded to multiples of 32 with zeros: x [B][Hin][Win][cin_pad], w [cout][cin][ks][ks] (PyTorch layout),
- * grad_y [B][Ho][Wo][cout_pad].  grad_x [B][Hin][Win][cin_pad] and / or grad_w [cout][cin][ks][ks] (either may be NULL).
- * prec 0 = fp32 MFMA, 2 = bf16x3. */
+ * grad_y [B][Ho][Wo][cout_pad].  grad_x [B][Hin][Win][cin_pad] and / or grad_w [cout][cin][ks][ks] (either may be NULL);
+ * grad_x_add (optional, same shape as grad_x, MAY ALIAS it) is added to the input gradient -- how the gradients of a tensor
+ * with several consumers are accumulated.  prec 0 = fp32 MFMA, 2 = bf16x3. */
 size_t opp_conv2d_backward_workspace_bytes(int B, int Hin, int Win, int cin, int cout, int ks, int stride, int prec);
 int opp_conv2d_backward_nhwc(const float* x, int B, int Hin, int Win, int cin, const float* w, int cout, int ks, int stride,
-                             const float* grad_y, float* grad_x, float* grad_w, int prec, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             const float* grad_y, float* grad_x, const float* grad_x_add, float* grad_w, int prec, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* Backward of nn.BatchNorm2d in train() followed by (+ residual) -> activation (backbone/resnet.py:25-26, :37-45) over an NHWC
  * tensor [rows][ld] with C real channels: y = act((raw - mean) * invstd * gamma + beta (+ res)); act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
  * grad_y, y (unused for act 0), raw, the forward's batch mean / invstd [ld] in; grad_raw (may alias grad_y), grad_res (optional,

@@ -124,7 +124,7 @@ SIGNATURES = {
     "opp_backbone_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p,
                                       c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "opp_conv2d_backward_workspace_bytes": (c_size_t, [c_int] * 8),
-    "opp_conv2d_backward_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+    "opp_conv2d_backward_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_size_t, c_void_p]),
     "opp_batchnorm_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
     "opp_batchnorm_backward_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -1958,7 +1958,8 @@ extern "C" size_t opp_conv2d_backward_workspace_bytes(int B, int Hin, int Win, i
 }
 
 extern "C" int opp_conv2d_backward_nhwc(const float* x, int B, int Hin, int Win, int cin, const float* w, int cout, int ks, int stride,
-                                        const float* grad_y, float* grad_x, float* grad_w, int prec, void* ws, size_t ws_bytes, void* stream) {
+                                        const float* grad_y, float* grad_x, const float* grad_x_add, float* grad_w, int prec, void* ws,
+                                        size_t ws_bytes, void* stream) {
   OPP_CHECK_ARG(x && w && grad_y && ws && (grad_x || grad_w), "conv2d_backward: null argument");
   OPP_CHECK_ARG(ks == 1 || ks == 3, "conv2d_backward: kernel size must be 1 or 3");
   ConvBwdNeed n;
@@ -1967,7 +1968,7 @@ extern "C" int opp_conv2d_backward_nhwc(const float* x, int B, int Hin, int Win,
   ConvBwdWs cw;
   conv_bwd_alloc(a, n, cw);
   OPP_CHECK_ARG(a.ok, "conv2d_backward: workspace too small");
-  return conv_backward(x, B, Hin, Win, cin, w, cout, ks, stride, grad_y, grad_x, nullptr, grad_w, prec, cw, (hipStream_t)stream);
+  return conv_backward(x, B, Hin, Win, cin, w, cout, ks, stride, grad_y, grad_x, grad_x_add, grad_w, prec, cw, (hipStream_t)stream);
 }
 
 extern "C" size_t opp_batchnorm_backward_workspace_bytes(int rows, int ld) { return opp_bn_bwd_scratch_bytes(rows, ld) + 256; }

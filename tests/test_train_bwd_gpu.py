@@ -44,6 +44,10 @@ def _rel(a, b):
     (2, 196, 256, 1, 1, 8, 8),        # lateral 1x1
     (1, 256, 256, 3, 1, 8, 8),
     (3, 64, 96, 3, 1, 5, 7),          # ragged sizes: pixel count not a multiple of 32
+    (2, 196, 256, 3, 2, 16, 24),      # layer3.0.conv1 at a 128 x 192 image, B = 2
+    (2, 196, 256, 1, 2, 16, 24),      # layer3.0.downsample
+    (2, 196, 196, 3, 1, 16, 24),      # layer2.1 convolutions
+    (2, 128, 196, 3, 2, 32, 48),      # layer2.0.conv1
 ])
 def test_conv2d_backward_vs_autograd(B, cin, cout, ks, stride, H, W, prec):
     from onepose_plus_plus_amd import _lib
@@ -61,15 +65,23 @@ def test_conv2d_backward_vs_autograd(B, cin, cout, ks, stride, H, W, prec):
     gw = torch.full((cout, cin, ks, ks), float("nan"), device="cuda")
     nb = lib.opp_conv2d_backward_workspace_bytes(B, H, W, cin, cout, ks, stride, prec)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
-    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), gx.data_ptr(),
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), gx.data_ptr(), None,
                                             gw.data_ptr(), prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
     torch.cuda.synchronize()
     assert _rel(_from_nhwc(gx, cin), xd.grad) < 5e-6, "grad_x"
+    # accumulation into a buffer that already holds another consumer's gradient (aliased, as the residual blocks use it)
+    add = torch.randn(B, H, W, cin_p, generator=g)
+    add[..., cin:] = 0
+    acc = add.cuda().contiguous()
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), acc.data_ptr(), acc.data_ptr(),
+                                            None, prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
+    torch.cuda.synchronize()
+    assert _rel(_from_nhwc(acc, cin), xd.grad + add[..., :cin].permute(0, 3, 1, 2).double()) < 5e-6, "grad_x + add (aliased)"
     assert (gx[..., cin:] == 0).all(), "padded channels of grad_x must be exact zeros"
     assert _rel(gw.cpu(), wd.grad) < 5e-6, "grad_w"
     # deterministic: fixed-order split reduction
     gw2 = torch.empty_like(gw)
-    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), None,
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, ks, stride, gyn.data_ptr(), None, None,
                                             gw2.data_ptr(), prec, ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
     torch.cuda.synchronize()
     assert torch.equal(gw, gw2)
@@ -91,7 +103,7 @@ def test_conv_wgrad_long_reduction():
     nb = lib.opp_conv2d_backward_workspace_bytes(B, H, W, cin, cout, 3, 1, 2)
     ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
     wdev = w.cuda()
-    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, 3, 1, gyn.data_ptr(), None, gw.data_ptr(), 2,
+    _lib.check(lib.opp_conv2d_backward_nhwc(xn.data_ptr(), B, H, W, cin, wdev.data_ptr(), cout, 3, 1, gyn.data_ptr(), None, None, gw.data_ptr(), 2,
                                             ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
     torch.cuda.synchronize()
     # error relative to sum |a||b| ~ sqrt(P) * 0.64: a few fp32 ulps of the largest partial sums

@@ -43,7 +43,7 @@ def main():
         for what, a, b in (("dgrad", gx, None), ("wgrad", None, gw)):
             def run():
                 _lib.check(lib.opp_conv2d_backward_nhwc(x.data_ptr(), B, H, H, cin, w.data_ptr(), cout, ks, stride, gy.data_ptr(),
-                                                        a.data_ptr() if a is not None else None, b.data_ptr() if b is not None else None, 2,
+                                                        a.data_ptr() if a is not None else None, None, b.data_ptr() if b is not None else None, 2,
                                                         ws.data_ptr(), nb, s), "conv2d_backward")
             for _ in range(2):
                 run()
