@@ -731,6 +731,7 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
         return (time.perf_counter() - t0) * 1e3
 
     def timed(fn):
+        fn()                                  # two untimed calls: code objects, allocator pools and workspaces reach steady state
         fn()
         torch.cuda.synchronize(dev)
         t = time.perf_counter()

@@ -555,8 +555,9 @@ struct SplitKScope {
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
              float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false) {
   OppGemm g;
-  g.splitk_ws = t_splitk_ws;
-  g.splitk_ws_floats = t_splitk_ws ? kSplitKScratchFloats : 0;
+  static const bool splitk_on = !(getenv("OPP_CONV_SPLITK") && getenv("OPP_CONV_SPLITK")[0] == '0');   // A/B switch of the tools
+  g.splitk_ws = splitk_on ? t_splitk_ws : nullptr;
+  g.splitk_ws_floats = g.splitk_ws ? kSplitKScratchFloats : 0;
   g.nonfinite = t_status_flag;
   g.tile_policy = t_tile_policy;
   g.conv = 1;
