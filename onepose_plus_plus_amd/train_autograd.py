@@ -1,18 +1,24 @@
-"""Backward of the train()-mode forward.
+"""The training step's forward + backward as a graph of hand-written HIP nodes.
 
 `PL_OnePosePlus.training_step` (src/lightning_model/OnePosePlus_lightning_model.py:54-81) runs `self.matcher(batch)`,
 then `fine_supervision` and the loss (`losses.py:114-142`), which differentiates two outputs of the matcher:
-`conf_matrix` (focal loss over all B x N x L entries) and `expec_f` (fine L2 loss).  The FORWARD of that step runs on
-the hand-written HIP path (`OnePosePlus_model._forward_train`: BatchNorm batch statistics, training branch of
-get_coarse_match, running-statistics update) and is what every returned value comes from.  The BACKWARD is only
-partly hand-written: `TrainForward` is a `torch.autograd.Function` whose `backward` re-evaluates the same graph on the
-same device from the saved inputs -- match indices frozen to the ones the HIP forward selected, BatchNorm again with
-batch statistics but WITHOUT touching the running statistics -- and lets `torch.autograd` walk it.  Nodes with a
-hand-written HIP backward: every Linear of the two transformers (`HipLinear`: forward, input gradient and split-K
-weight gradient on the MFMA GEMM, csrc/linear_bwd.hip), the dual softmax (`DualSoftmax`, csrc/loss.hip) and the focal
-loss (losses.py); convolutions, BatchNorm, LayerNorm and the attention einsums still differentiate through PyTorch ops.
-This file is that differentiable restatement (functional, flat parameter dict); it is used for gradients only, never
-for forward values, and is independent of the test-side oracle.
+`conf_matrix` (focal loss over all B x N x L entries) and `expec_f` (fine L2 loss).  With gradients enabled,
+`OnePosePlus_model._forward_train(graph=True)` builds the forward ONCE out of `torch.autograd.Function` nodes whose forward AND
+backward are kernels of libopp_hip.so -- nothing is re-evaluated in the backward, and no convolution / GEMM / normalisation of
+the step runs in a PyTorch (MIOpen / rocBLAS) operator:
+  `HipBackbone`         ResNet-FPN with BatchNorm batch statistics; activations kept on a tape; backward = convolution
+                        input / weight gradients, BatchNorm + activation backward, upsample transpose (csrc/conv_bwd.hip)
+  `HipLinear`           every Linear of the two transformers and of the keypoint encoder (csrc/linear_bwd.hip)
+  `HipLinearAttention`  csrc/linattn_train.hip
+  `HipLayerNorm`        csrc/train_misc.hip
+  `HipCoarseMatch`      score GEMM + dual softmax + mutual-nearest-neighbour selection = the inference kernels (opp_coarse_match);
+                        backward = dual-softmax backward (csrc/loss.hip) + the two feature gradients on the Linear-backward GEMMs
+  `HipFineGather`       5 x 5 windows of the fine map; backward scatters (csrc/train_misc.hip)
+PyTorch supplies the tape (autograd), elementwise glue (residual adds, ReLU, the 25-cell expectation head) and index plumbing.
+
+`differentiable_forward` is the same graph as a functional restatement on plain torch ops: the CPU tests differentiate it against
+the reference's own gradients (tests/test_train_autograd_cpu.py); it is independent of the test-side oracle and is NOT on the
+device path.
 
 Each function cites the reference code it differentiates (paths relative to src/models/OnePosePlus/).
 """
@@ -397,6 +403,7 @@ class HipBackbone(torch.autograd.Function):
                                                tape.data_ptr(), tape.numel(), ws.data_ptr(), ws.numel(), stream), "opp_backbone_train_tape")
         model._update_running_stats(lib, c, stats)
         ctx.model, ctx.img, ctx.tape, ctx.table_idx = model, img, tape, table_idx
+        ctx.c_ctx = c                                                    # the C context whose packed weights / BatchNorm pointers the tape belongs to
         ctx.ptrs, ctx.keep = model._rt["ptrs"], model._rt["keep"]       # the weight table the tape's forward ran on (kept alive)
         ctx.geom = (B, H, W)
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -409,6 +416,9 @@ class HipBackbone(torch.autograd.Function):
         lib = _lib.load()
         model = ctx.model
         c = model._rt["ctx"]
+        if c is not ctx.c_ctx or ctx.tape is None:
+            raise RuntimeError("HipBackbone.backward: the module's runtime was re-created (set_gemm_precision / .to()) or the graph was "
+                               "already differentiated between this step's forward and backward")
         dev = ctx.img.device
         B, H, W = ctx.geom
         ptrs, n = ctx.ptrs
