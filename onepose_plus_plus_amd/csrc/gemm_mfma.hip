@@ -1031,7 +1031,8 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int DEPTH, int PREC>
 int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   // split-operand variants are built for the 64/128/256-column tiles (bf16x3: 12 x 16 B weight slots per row
-  // must divide over the workgroup; its 4-wave 128x128 tile would not fit the register file)
+  // must divide over the workgroup; its 4-wave 128x128 tile (one wave per SIMD, 204 + 64 registers, no spills) was built and
+  // measured in round 4: 5 .. 20 % SLOWER than the 8-wave tile on every layer shape (profiles/r04_conv_bench_4wave_128x128.txt))
   // split-operand variants are instantiated for the tiles their policies can pick only (depth 2: deeper prefetch measured
   // no better with the shorter MFMA phase; the 4-wave 128-column tiles are fp32 tiles)
   // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
