@@ -554,13 +554,13 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
                      "us_per_forward": round(ms * 1e3 / nsteps, 1), "alg_mbytes_per_launch": round(by / n / 1e6, 3)})
     if not meas:
         return None
-    # launches shorter than 15 us: the event pair around them reads `event_pair_us` even for an EMPTY kernel (whose own duration in
-    # the rocprofv3 kernel trace is kEmptyKernelUs), so the part of a reading that is not the kernel is event_pair_us - kEmptyKernelUs
+    # the event pair around a launch reads `event_pair_us` even for an EMPTY kernel (whose own duration in the rocprofv3 kernel
+    # trace is EMPTY_KERNEL_US), so event_pair_us - EMPTY_KERNEL_US of every reading is not the kernel: 30 ... 60 % of a sub-15-us
+    # launch, 5 ... 15 % of a 40-us one.  `frac` stays the raw reading; `frac_event_corrected` is what the kernel trace shows.
     for m in meas:
-        if m["avg_launch_us"] < 15.0:
-            t = max(m["avg_launch_us"] - max(event_pair_us - EMPTY_KERNEL_US, 0.0), 0.25 * m["avg_launch_us"])
-            m["avg_launch_us_event_corrected"] = round(t, 2)
-            m["frac_event_corrected"] = round(m["frac"] * m["avg_launch_us"] / t, 4)
+        t = max(m["avg_launch_us"] - max(event_pair_us - EMPTY_KERNEL_US, 0.0), 0.25 * m["avg_launch_us"])
+        m["avg_launch_us_event_corrected"] = round(t, 2)
+        m["frac_event_corrected"] = round(m["frac"] * m["avg_launch_us"] / t, 4)
     meas.sort(key=lambda m: -m["us_per_forward"])
     # the line stays short enough for log tails: strings every entry shares are kept once, on the dominant kernel's entry
     src = None
@@ -575,8 +575,8 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
         roof["traffic_source"] = src
     roof["other_kernels"] = meas[1:]
     roof["event_pair_us"] = round(event_pair_us, 2)
-    roof["event_correction"] = ("symbols under 15 us per launch also carry frac_event_corrected: time minus (event_pair_us - %.1f us), the reading "
-                                "of an empty kernel between two events minus its duration in the kernel trace" % EMPTY_KERNEL_US)
+    roof["event_correction"] = ("frac_event_corrected: launch time minus (event_pair_us - %.1f us) = the reading of an empty kernel between two "
+                                "events minus its duration in the kernel trace" % EMPTY_KERNEL_US)
     return roof
 
 

@@ -103,6 +103,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_kernel(const OppGemmSS g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
+  // two workgroups share a CU: a static priority for every other workgroup of an XCD de-phases the pair (one's MFMA loop
+  // under the other's prologue / epilogue).  blockIdx is scalar: the branch is wave-uniform, as s_setprio requires.
+  if (g.prio_mode == 1 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(1);
+  if (g.prio_mode == 2 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(3);
 
   // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only -- every output is indexed by tile coordinates): an XCD gets
   // a contiguous range of a linear order that walks STRIPS of RS row panels column by column (row fastest).  The ~64 tiles an
@@ -575,6 +579,10 @@ int opp_gemm_ss_tile_cols() { return BN; }
 
 int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
   OppGemmSS g = g_in;
+  {
+    static const int prio_env = getenv("OPP_SS_PRIO") ? atoi(getenv("OPP_SS_PRIO")) : 0;
+    g.prio_mode = prio_env;
+  }
   OPP_CHECK_ARG(g.A && g.B && g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm_ss: bad operands / K %% 32 (M %d N %d K %d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.lda % 16 == 0 && g.ldb % 16 == 0 && g.lda >= g.K * 6 && g.ldb >= g.K * 6, "gemm_ss: operand row strides are bytes, >= 6 K, 16-byte multiples");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

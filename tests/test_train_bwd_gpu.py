@@ -395,3 +395,76 @@ def test_linear_weight_gradient_on_the_pixel_major_kernel(M, N, K):
                "opp_linear_backward")
     torch.cuda.synchronize()
     assert float((dw2.cpu().double() - 2 * want_w).abs().max()) < 6e-6 * M ** 0.5      # accumulate_grad_w
+
+
+def _train_variant(name, precision, fine, with_mask):
+    """-> (results of the graph forward with gradients, results of the fused no-grad train()-mode forward, model of the graph run)"""
+    from onepose_plus_plus_amd.config import default_config
+    from tests import helpers as H
+    from tests import hip_ops as ops
+    cfg, sd, data = H.train_setup(name)
+    gold = H.load_golden(name)
+    cfg_v = default_config(thr=cfg["coarse_matching"]["thr"], fine=fine)
+    cfg_v["coarse_matching"]["train"] = cfg["coarse_matching"]["train"]
+    B, _, Himg, Wimg = data["query_image"].shape
+    if with_mask:
+        m = torch.ones(B, Himg // 8, Wimg // 8)
+        m[0, :, -3:] = 0                                  # padded right border of sample 0
+        m[-1, -2:, :] = 0                                 # padded bottom rows of the last sample
+        data["query_image_mask"] = m
+        gt = data["conf_matrix_gt"].view(B, -1, Himg // 8, Wimg // 8)
+        gt[0, :, :, -3:] = 0                              # no ground truth on padding
+        gt[-1, :, -2:, :] = 0
+    outs = []
+    for graph in (True, False):
+        model = ops.make_model(cfg_v, sd, precision)
+        model.train()
+        model.train_randint = H.RecordedRandint([gold["randint_%d" % i] for i in range(int(gold["n_randint"]))]) if not with_mask else \
+            (lambda high, size, device=None, **kw: (torch.arange(size[0]) % high).to(device))
+        d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+        if graph:
+            out = model(d)
+            assert out is d
+        else:
+            with torch.no_grad():
+                model(d)
+        outs.append((d, model))
+    torch.cuda.synchronize()
+    return outs[0][0], outs[1][0], outs[0][1]
+
+
+@pytest.mark.parametrize("precision,fine,with_mask", [("fp32", True, False), ("bf16x3", False, False), ("bf16x3", True, True), ("fp32", True, True)])
+def test_training_graph_matches_the_fused_train_forward(precision, fine, with_mask):
+    """The graph of HIP nodes (gradients enabled) and the fused train()-mode forward (no_grad; pinned to the reference by the train
+    fixtures) are the same function: same matches, confidences and fine offsets within the forward tolerances -- in the fp32
+    arithmetic, without the fine level, and with a `query_image_mask` (masked cells keep zero confidence and get no gradient); every
+    parameter that takes part receives a finite gradient."""
+    from tests import helpers as H
+    g, f, model = _train_variant("train_b4_64x96_n150", precision, fine, with_mask)
+    assert torch.equal(g["b_ids"], f["b_ids"]) and torch.equal(g["i_ids"], f["i_ids"]) and torch.equal(g["j_ids"], f["j_ids"])
+    assert float((g["conf_matrix"].detach() - f["conf_matrix"]).abs().max()) <= H.TOL_CONF
+    assert float((g["mconf"].detach() - f["mconf"]).abs().max()) <= H.TOL_CONF
+    assert g["conf_matrix"].requires_grad
+    loss = (g["conf_matrix"] * torch.rand_like(g["conf_matrix"])).sum()
+    if fine:
+        assert float((g["expec_f"].detach()[:, :2] - f["expec_f"][:, :2]).abs().max()) <= H.TOL_OFFSET
+        assert float((g["mkpts_query_f"] - f["mkpts_query_f"]).abs().max()) <= H.TOL_PIXEL
+        loss = loss + (g["expec_f"] ** 2).sum()
+    else:
+        assert "expec_f" not in g or not torch.is_tensor(g.get("expec_f")) or not g["expec_f"].requires_grad
+    if with_mask:
+        mk = g["query_image_mask"].flatten(-2)                                  # [B, L]
+        assert float(g["conf_matrix"].detach()[(mk == 0)[:, None, :].expand_as(g["conf_matrix"])].abs().max()) < 1e-30
+    loss.backward()
+    n = 0
+    for name, p in model.named_parameters():
+        if not fine and name.startswith("loftr_fine."):
+            assert p.grad is None
+            continue
+        if not fine and name.startswith(("backbone.layer1_outconv", "backbone.layer2_outconv")):
+            # coarse only: the FPN fine branch has no consumer -> zero (not missing) gradients from the backbone node
+            assert p.grad is not None and float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
+        n += 1
+    assert n > 100
