@@ -4,6 +4,9 @@ set -x
 cd $GRAFT_REPO_ROOT
 bash tools/pmc_bench.sh gpurun_out/final_pmc
 python tools/pmc_traffic_summary.py gpurun_out/final_pmc gpurun_out/final_pmc_traffic.csv profiles/traffic_symbols_bf16x3.json > /dev/null
+cp profiles/traffic_symbols_bf16x3.json gpurun_out/final_traffic_symbols_bf16x3.json     # profiles/ does not travel back; gpurun_out/ does
+bash tools/pmc_mfma.sh gpurun_out/final_pmc_mfma > /dev/null 2>&1
+python tools/pmc_mfma_summary.py gpurun_out/final_pmc_mfma gpurun_out/final_pmc_mfma_util.csv > gpurun_out/final_pmc_mfma_util.txt 2>&1
 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_default.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_driver.json 2> gpurun_out/final_bench_driver.err
 python tools/smi_trace.py --out gpurun_out/final_smi -- python bench.py --steps 200 --warmup 5 --cpu-seconds 0 --no-legs --no-roofline > gpurun_out/final_smi.log 2>&1
@@ -13,5 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --images-per-step 1 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_fine -o fine -- python $GRAFT_REPO_ROOT/tools/fine_profile.py > $GRAFT_REPO_ROOT/gpurun_out/final_fine.log 2>&1
-cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv
+cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv gpurun_out/final_fine/*trace.csv
+rm -rf gpurun_out/final_pmc/FETCH_SIZE/*trace.csv gpurun_out/final_pmc/WRITE_SIZE/*trace.csv gpurun_out/final_pmc_mfma/mfma/*trace.csv
+(timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -15) > gpurun_out/final_gpu_tests.txt
 ls gpurun_out/final_s1 gpurun_out/final_s3 gpurun_out/final_fine gpurun_out/final_pmc
