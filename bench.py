@@ -91,7 +91,7 @@ MFMA_SYMBOLS = [
     (1014, "opp_gemm_kernel<128, 128, 4, 2, true> x 4 K slices", "3x3 convolutions of the 1/8-resolution stage (4096 pixels, K = 1792 .. 2304) as "
                                                                   "four K slices on 8-wave tiles: 256 workgroups instead of 64 four-wave ones"),
 ]
-EMPTY_KERNEL_US = 1.5        # duration of opp_empty_kernel in the rocprofv3 kernel trace (profiles/r04_kernel_stats_*.csv)
+EMPTY_KERNEL_US = 3.6        # average duration of opp_empty_kernel in the rocprofv3 kernel trace (profiles/r04_kernel_stats_bench_streams1.csv)
 HBM_SYMBOLS = [
     (1000, "linattn_kv_mfma_kernel", "linear-attention gather: sum_s phi(K_s)^T V_s (K, V read once + chunk partials written)"),
     (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
