@@ -704,7 +704,8 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
     OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
     OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
-    OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp));
+    static const int l1out_cfg = getenv("OPP_L1OUT_CFG") ? atoi(getenv("OPP_L1OUT_CFG")) : -1;   // A/B switch (tools): tile of the K = 128 lateral
+    OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp, hp == OPP_PREC_BF16X3 ? l1out_cfg : -1));
     OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
     OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp));
   }
