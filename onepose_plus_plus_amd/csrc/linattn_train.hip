@@ -24,6 +24,19 @@ constexpr int kThreads = 256;
 __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 __device__ __forceinline__ float dphi(float x) { return x > 0.f ? 1.f : __expf(x); }
 
+// sum over the D (= 32 or 16) consecutive lanes that share one token: fixed butterfly order, every lane of the group gets the sum
+template <int D>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = D / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// r03 ran the per-token matrix-vector products (num = Qp KV, g . num, the two D x D back-projections) on kTok = 64 of the 256
+// threads, 1000+ dependent FMAs each: the kernels were latency-bound at 0.9 TB/s.  Since r04 a token is a GROUP OF D LANES
+// (lane = output channel): every thread works in every phase, the D x D operand is read conflict-free from LDS in the layout each
+// product needs (both KV and KV^T are staged), the per-token scalars are D-lane butterflies -- no per-token LDS round trips.
+
 // partial KV / ks of one chunk of source tokens: a[t][d] (x) b[t][v] summed over t.  MODE 0: a = Kp, b = Vs (forward);
 // MODE 1: a = Qp, b = gnum, and the vector partial is sum_t gden[t] Qp[t] (backward; needs KV, ks of the forward)
 template <int D, int MODE>
@@ -58,21 +71,19 @@ __global__ __launch_bounds__(kThreads) void la_outer_kernel(const float* __restr
   }
   __syncthreads();
   if (MODE == 1) {
-    // per token: den, num . g  ->  gnum = g S / den (overwrites b_sh), gden
-    for (int t = tid; t < kTok; t += kThreads) {
-      float den = eps, dot = 0.f;
-#pragma unroll 4
-      for (int d = 0; d < D; ++d) den = fmaf(a_sh[t][d], ks_sh[d], den);
-      for (int v = 0; v < D; ++v) {
-        float num = 0.f;
-#pragma unroll 4
-        for (int d = 0; d < D; ++d) num = fmaf(a_sh[t][d], kv_sh[d * D + v], num);
-        dot = fmaf(b_sh[t][v], num, dot);
-      }
+    // per token (group of D lanes, lane = v): num_v = Qp . KV[:, v], den = Qp . ks + eps, dot = g . num
+    //   -> gnum = g S / den (overwrites b_sh), gden = -(dot S) / den^2
+    for (int i = tid; i < kTok * D; i += kThreads) {
+      const int t = i / D, v = i - t * D;
+      float num = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < D; ++d) num = fmaf(a_sh[t][d], kv_sh[d * D + v], num);
+      const float gv = b_sh[t][v];
+      const float dot = group_sum<D>(gv * num);
+      const float den = group_sum<D>(a_sh[t][v] * ks_sh[v]) + eps;
       const float z = 1.0f / den;
-      w_sh[t] = -(dot * s_len) * z * z;
-      const float sc = s_len * z;
-      for (int v = 0; v < D; ++v) b_sh[t][v] *= sc;
+      b_sh[t][v] = gv * (s_len * z);
+      if (v == 0) w_sh[t] = -(dot * s_len) * z * z;
     }
     __syncthreads();
   }
@@ -92,15 +103,24 @@ __global__ __launch_bounds__(kThreads) void la_outer_kernel(const float* __restr
   }
 }
 
-// out[bh][e] = sum over chunks in chunk order
-__global__ void la_chunk_reduce_kernel(const float* __restrict__ part, int nchunks, int per, size_t n_bh, float* __restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_bh * per) return;
-  const size_t bh = i / per;
-  const int e = (int)(i - bh * per);
+// out[bh][e] = sum over the chunks: four interleaved slices per output (slice s adds chunks s, s + 4, ... in ascending order), then
+// (s0 + s1) + (s2 + s3) -- fixed order, deterministic; four lanes per output instead of one thread walking ~110 partials
+__global__ __launch_bounds__(256) void la_chunk_reduce_kernel(const float* __restrict__ part, int nchunks, int per, size_t n_bh,
+                                                              float* __restrict__ out) {
+  const size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t i = gi >> 2;
+  const int sl = (int)(gi & 3);
   float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += part[(bh * nchunks + c) * per + e];
-  out[i] = s;
+  const bool live = i < n_bh * per;
+  if (live) {
+    const size_t bh = i / per;
+    const int e = (int)(i - bh * per);
+    for (int c = sl; c < nchunks; c += 4) s += part[(bh * nchunks + c) * per + e];
+  }
+  const float s1 = __shfl_xor(s, 1, 64);
+  const float pair = (sl & 1) ? s1 + s : s + s1;          // both lanes of a pair: (even slice) + (odd slice)
+  const float other = __shfl_xor(pair, 2, 64);
+  if (live && sl == 0) out[i] = pair + other;              // (s0 + s1) + (s2 + s3)
 }
 
 // per query token: MODE 0 forward out = num / den * S ; MODE 1 backward gq = (gnum KV^T + gden ks) phi'(q) mq
@@ -108,12 +128,16 @@ template <int D, int MODE>
 __global__ __launch_bounds__(kThreads) void la_query_kernel(const float* __restrict__ q, const float* __restrict__ g, const float* __restrict__ mask,
                                                             const float* __restrict__ kv, const float* __restrict__ ks, int T, int H,
                                                             float s_len, float eps, float* __restrict__ out) {
-  __shared__ float q_sh[kTok][D + 1], g_sh[kTok][D + 1], kv_sh[D * D], ks_sh[D], z_sh[kTok], gd_sh[kTok];
+  __shared__ float q_sh[kTok][D + 1], g_sh[MODE == 1 ? kTok : 1][D + 1], kv_sh[D * D], kvt_sh[MODE == 1 ? D * D : 1], ks_sh[D];
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t0 = chunk * kTok, nt = min(kTok, T - t0);
   const int tid = threadIdx.x;
   const size_t row = (size_t)H * D;
-  for (int i = tid; i < D * D; i += kThreads) kv_sh[i] = kv[((size_t)b * H + h) * D * D + i];
+  for (int i = tid; i < D * D; i += kThreads) {
+    const float val = kv[((size_t)b * H + h) * D * D + i];
+    kv_sh[i] = val;
+    if (MODE == 1) kvt_sh[(i % D) * D + i / D] = val;      // KV^T: the back-projection reads it with lane = row of KV
+  }
   if (tid < D) ks_sh[tid] = ks[((size_t)b * H + h) * D + tid];
   for (int i = tid; i < kTok * D; i += kThreads) {
     const int t = i / D, d = i - t * D;
@@ -125,44 +149,32 @@ __global__ __launch_bounds__(kThreads) void la_query_kernel(const float* __restr
       if (MODE == 1) gv = g[o];
     }
     q_sh[t][d] = qv;
-    g_sh[t][d] = gv;
+    if (MODE == 1) g_sh[t][d] = gv;
   }
   __syncthreads();
-  for (int t = tid; t < kTok; t += kThreads) {
-    float den = eps;
-#pragma unroll 4
-    for (int d = 0; d < D; ++d) den = fmaf(q_sh[t][d], ks_sh[d], den);
-    const float z = 1.0f / den;
-    z_sh[t] = z;
-    if (MODE == 1) {
-      float dot = 0.f;
-      for (int v = 0; v < D; ++v) {
-        float num = 0.f;
-#pragma unroll 4
-        for (int d = 0; d < D; ++d) num = fmaf(q_sh[t][d], kv_sh[d * D + v], num);
-        dot = fmaf(g_sh[t][v], num, dot);
-      }
-      gd_sh[t] = -(dot * s_len) * z * z;
-    }
-  }
-  __syncthreads();
+  // a token = D consecutive lanes, lane = output channel e
   for (int i = tid; i < kTok * D; i += kThreads) {
     const int t = i / D, e = i - t * D;
-    if (t >= nt) continue;
-    const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + e;
+    float num = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < D; ++d) num = fmaf(q_sh[t][d], kv_sh[d * D + e], num);
+    const float den = group_sum<D>(q_sh[t][e] * ks_sh[e]) + eps;
+    const float z = 1.0f / den;
+    const size_t o = ((size_t)b * T + t0 + min(t, nt - 1)) * row + (size_t)h * D + e;
     if (MODE == 0) {
-      float num = 0.f;
-#pragma unroll 4
-      for (int d = 0; d < D; ++d) num = fmaf(q_sh[t][d], kv_sh[d * D + e], num);
-      out[o] = (num * z_sh[t]) * s_len;
+      if (t < nt) out[o] = (num * z) * s_len;
     } else {
+      const float dot = group_sum<D>(g_sh[t][e] * num);
+      const float gd = -(dot * s_len) * z * z;
+      const float sc = s_len * z;
       // gQp[e] = sum_v gnum[v] KV[e][v] + gden ks[e]
-      const float sc = s_len * z_sh[t];
-      float acc = gd_sh[t] * ks_sh[e];
-#pragma unroll 4
-      for (int v = 0; v < D; ++v) acc = fmaf(g_sh[t][v] * sc, kv_sh[e * D + v], acc);
-      const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
-      out[o] = acc * dphi(q[o]) * m;
+      float acc = gd * ks_sh[e];
+#pragma unroll 8
+      for (int v = 0; v < D; ++v) acc = fmaf(g_sh[t][v] * sc, kvt_sh[v * D + e], acc);
+      if (t < nt) {
+        const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
+        out[o] = acc * dphi(q[o]) * m;
+      }
     }
   }
 }
@@ -172,12 +184,16 @@ template <int D>
 __global__ __launch_bounds__(kThreads) void la_source_bwd_kernel(const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ mask,
                                                                  const float* __restrict__ gkv, const float* __restrict__ gks, int T, int H, float inv_s,
                                                                  float* __restrict__ gk, float* __restrict__ gv) {
-  __shared__ float k_sh[kTok][D + 1], v_sh[kTok][D + 1], kv_sh[D * D], ks_sh[D];
+  __shared__ float k_sh[kTok][D + 1], v_sh[kTok][D + 1], kv_sh[D * D], kvt_sh[D * D], ks_sh[D];
   const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int t0 = chunk * kTok, nt = min(kTok, T - t0);
   const int tid = threadIdx.x;
   const size_t row = (size_t)H * D;
-  for (int i = tid; i < D * D; i += kThreads) kv_sh[i] = gkv[((size_t)b * H + h) * D * D + i];
+  for (int i = tid; i < D * D; i += kThreads) {
+    const float val = gkv[((size_t)b * H + h) * D * D + i];
+    kv_sh[i] = val;
+    kvt_sh[(i % D) * D + i / D] = val;
+  }
   if (tid < D) ks_sh[tid] = gks[((size_t)b * H + h) * D + tid];
   for (int i = tid; i < kTok * D; i += kThreads) {
     const int t = i / D, d = i - t * D;
@@ -198,9 +214,9 @@ __global__ __launch_bounds__(kThreads) void la_source_bwd_kernel(const float* __
     const size_t o = ((size_t)b * T + t0 + t) * row + (size_t)h * D + e;
     const float m = mask ? mask[(size_t)b * T + t0 + t] : 1.f;
     float a = ks_sh[e], c = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = 0; j < D; ++j) {
-      a = fmaf(v_sh[t][j], kv_sh[e * D + j], a);     // gKp[e] = sum_v Vs[v] gKV[e][v] + gks[e]
+      a = fmaf(v_sh[t][j], kvt_sh[j * D + e], a);    // gKp[e] = sum_v Vs[v] gKV[e][v] + gks[e]   (gKV^T read with lane = e)
       c = fmaf(k_sh[t][j], kv_sh[j * D + e], c);     // gVs[e] = sum_d Kp[d] gKV[d][e]
     }
     gk[o] = a * dphi(k[o]) * m;
@@ -231,8 +247,8 @@ int fwd_impl(const float* q, const float* k, const float* v, const float* qm, co
   hipLaunchKernelGGL((la_outer_kernel<D, 0>), dim3(p.cs, H, B), dim3(kThreads), 0, st, k, v, km, (const float*)nullptr, (const float*)nullptr, S, H,
                      inv_s, s_len, eps, ws + p.off_pm, ws + p.off_pv);
   const size_t nbh = (size_t)B * H;
-  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cs, D * D, nbh, kv);
-  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cs, D, nbh, ks);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D * 4 + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cs, D * D, nbh, kv);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * 4 + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cs, D, nbh, ks);
   hipLaunchKernelGGL((la_query_kernel<D, 0>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, (const float*)nullptr, qm, kv, ks, L, H, s_len, eps, out);
   OPP_CHECK_LAUNCH("linattn_train forward");
   return OPP_OK;
@@ -248,8 +264,8 @@ int bwd_impl(const float* q, const float* k, const float* v, const float* qm, co
   float* gks = gkv + nbh * D * D;
   hipLaunchKernelGGL((la_outer_kernel<D, 1>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, g, qm, kv, ks, L, H, inv_s, s_len, eps, ws + p.off_pm,
                      ws + p.off_pv);
-  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cq, D * D, nbh, gkv);
-  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cq, D, nbh, gks);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * D * 4 + 255) / 256)), dim3(256), 0, st, ws + p.off_pm, p.cq, D * D, nbh, gkv);
+  hipLaunchKernelGGL(la_chunk_reduce_kernel, dim3((unsigned)((nbh * D * 4 + 255) / 256)), dim3(256), 0, st, ws + p.off_pv, p.cq, D, nbh, gks);
   hipLaunchKernelGGL((la_query_kernel<D, 1>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, g, qm, kv, ks, L, H, s_len, eps, gq);
   hipLaunchKernelGGL((la_source_bwd_kernel<D>), dim3(p.cs, H, B), dim3(kThreads), 0, st, k, v, km, gkv, gks, S, H, inv_s, gk, gv);
   OPP_CHECK_LAUNCH("linattn_train backward");
