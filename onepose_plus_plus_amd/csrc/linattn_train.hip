@@ -224,6 +224,167 @@ __global__ __launch_bounds__(kThreads) void la_source_bwd_kernel(const float* __
   }
 }
 
+// ---- short segments (the fine level: 25 window tokens against 1 point token per match, thousands of matches) ------------------
+// The chunked kernels above spend a workgroup on a (sample, head) pair and three extra launches on partial sums that a short
+// segment does not need.  Here ONE workgroup owns a sample with all its heads (H x 32 threads; a head = 32 lanes = 32 / D tokens
+// in flight): K, V, Q (and the gradient) of the sample are staged once, KV / ks (forward) and gKV / gks (backward) live in LDS,
+// every token sum runs in token order (deterministic), and a pass is one launch: forward 4 -> 1, backward 5 -> 1.
+constexpr int kSmallTok = 32;      // L, S <= 32
+
+struct SmallArgs {
+  const float *q, *k, *v, *qm, *km, *kv, *ks, *g;
+  float *out, *kv_out, *ks_out, *gq, *gk, *gv;
+  int L, S, H;
+  float inv_s, s_len, eps;
+};
+
+template <int D, bool BWD>
+__global__ __launch_bounds__(256) void la_small_kernel(const SmallArgs a) {
+  extern __shared__ float sm[];
+  const int L = a.L, S = a.S, H = a.H, C = H * D, DD = D * D;
+  float* q_sh = sm;                       // [L][C]   phi(q) mq
+  float* k_sh = q_sh + L * C;             // [S][C]   phi(k) mk
+  float* v_sh = k_sh + S * C;             // [S][C]   v mk / S
+  float* kv_sh = v_sh + S * C;            // [H][D][D]
+  float* ks_sh = kv_sh + H * DD;          // [H][D]
+  float* g_sh = ks_sh + C;                // backward: [L][C] g, then gnum in place
+  float* kvt_sh = g_sh + (BWD ? L * C : 0);      // backward: KV^T, later gKV^T
+  float* gd_sh = kvt_sh + (BWD ? H * DD : 0);    // backward: [L][H] gden
+  float* gks_sh = gd_sh + (BWD ? L * H : 0);     // backward: [H][D]
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const size_t qb = (size_t)b * L * C, sb = (size_t)b * S * C;
+  for (int i = tid; i < L * C; i += nthr) {
+    const float m = a.qm ? a.qm[(size_t)b * L + i / C] : 1.f;
+    q_sh[i] = phi(a.q[qb + i]) * m;
+    if (BWD) g_sh[i] = a.g[qb + i];
+  }
+  for (int i = tid; i < S * C; i += nthr) {
+    const float m = a.km ? a.km[(size_t)b * S + i / C] : 1.f;
+    k_sh[i] = phi(a.k[sb + i]) * m;
+    v_sh[i] = a.v[sb + i] * m * a.inv_s;
+  }
+  if (BWD) {     // KV, ks of the forward come back from the caller
+    for (int i = tid; i < H * DD; i += nthr) {
+      const float val = a.kv[(size_t)b * H * DD + i];
+      kv_sh[i] = val;
+      const int h = i / DD, r = i - h * DD;
+      kvt_sh[h * DD + (r % D) * D + r / D] = val;
+    }
+    for (int i = tid; i < C; i += nthr) ks_sh[i] = a.ks[(size_t)b * C + i];
+  }
+  __syncthreads();
+  if (!BWD) {
+    for (int i = tid; i < H * DD; i += nthr) {
+      const int h = i / DD, r = i - h * DD, d = r / D, vv = r - d * D;
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc = fmaf(k_sh[s * C + h * D + d], v_sh[s * C + h * D + vv], acc);
+      kv_sh[i] = acc;
+      a.kv_out[(size_t)b * H * DD + i] = acc;
+    }
+    for (int i = tid; i < C; i += nthr) {
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += k_sh[s * C + i];
+      ks_sh[i] = acc;
+      a.ks_out[(size_t)b * C + i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * C; i += nthr) {
+      const int l = i / C, c = i - l * C, h = c / D, e = c - h * D;
+      const float* qr = q_sh + l * C + h * D;
+      float num = 0.f, den = a.eps;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        num = fmaf(qr[d], kv_sh[h * DD + d * D + e], num);
+        den = fmaf(qr[d], ks_sh[h * D + d], den);
+      }
+      a.out[qb + i] = (num * (1.0f / den)) * a.s_len;
+    }
+    return;
+  }
+  // ---- backward -------------------------------------------------------------------------------------------------------------
+  // query tokens: item = (l, h, e) with the D channels of a (token, head) on D consecutive lanes
+  const int items_q = ((L * C + 63) / 64) * 64;          // whole waves take part in the butterflies
+  for (int i = tid; i < items_q; i += nthr) {
+    const bool live = i < L * C;
+    const int ii = live ? i : 0;
+    const int l = ii / C, c = ii - l * C, h = c / D, e = c - h * D;
+    const float* qr = q_sh + l * C + h * D;
+    const float* gr = g_sh + l * C + h * D;
+    float num = 0.f, den = a.eps;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      num = fmaf(qr[d], kv_sh[h * DD + d * D + e], num);
+      den = fmaf(qr[d], ks_sh[h * D + d], den);
+    }
+    const float ge = gr[e];
+    const float dot = group_sum<D>(live ? ge * num : 0.f);
+    const float z = 1.0f / den;
+    const float gd = -(dot * a.s_len) * z * z;
+    const float sc = a.s_len * z;
+    float acc = gd * ks_sh[h * D + e];
+#pragma unroll
+    for (int v = 0; v < D; ++v) acc = fmaf(gr[v] * sc, kvt_sh[h * DD + v * D + e], acc);
+    if (live) {
+      const float m = a.qm ? a.qm[(size_t)b * L + l] : 1.f;
+      a.gq[qb + i] = acc * dphi(a.q[qb + i]) * m;
+      if (e == 0) gd_sh[l * H + h] = gd;
+    }
+    // gnum overwrites g in place only after every lane of the group has read its row: the butterflies above are that point for
+    // the lanes of this group, and no other group touches this (token, head) row
+    __builtin_amdgcn_wave_barrier();
+    if (live) g_sh[i] = ge * sc;
+  }
+  __syncthreads();
+  // gKV = sum_l Qp[l]^T gnum[l], gks = sum_l gden[l] Qp[l]   (token order)
+  for (int i = tid; i < H * DD; i += nthr) {
+    const int h = i / DD, r = i - h * DD, d = r / D, vv = r - d * D;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc = fmaf(q_sh[l * C + h * D + d], g_sh[l * C + h * D + vv], acc);
+    kv_sh[i] = acc;
+    kvt_sh[h * DD + vv * D + d] = acc;
+  }
+  for (int i = tid; i < C; i += nthr) {
+    const int h = i / D;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc = fmaf(gd_sh[l * H + h], q_sh[l * C + i], acc);
+    gks_sh[i] = acc;
+  }
+  __syncthreads();
+  for (int i = tid; i < S * C; i += nthr) {
+    const int s = i / C, c = i - s * C, h = c / D, e = c - h * D;
+    const float m = a.km ? a.km[(size_t)b * S + s] : 1.f;
+    const float* kr = k_sh + s * C + h * D;
+    const float* vr = v_sh + s * C + h * D;
+    float ga = gks_sh[h * D + e], gc = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      ga = fmaf(vr[j], kvt_sh[h * DD + j * D + e], ga);      // gKp[e] = sum_v Vs[v] gKV[e][v] + gks[e]
+      gc = fmaf(kr[j], kv_sh[h * DD + j * D + e], gc);       // gVs[e] = sum_d Kp[d] gKV[d][e]
+    }
+    a.gk[sb + i] = ga * dphi(a.k[sb + i]) * m;
+    a.gv[sb + i] = gc * m * a.inv_s;
+  }
+}
+
+bool small_ok(int L, int S, int H, int D) { return L <= kSmallTok && S <= kSmallTok && H * 32 <= 256 && H >= 1 && (D == 16 || D == 32); }
+
+size_t small_lds(int L, int S, int H, int D, bool bwd) {
+  const size_t C = (size_t)H * D, DD = (size_t)D * D;
+  size_t f = L * C + 2 * S * C + H * DD + C;
+  if (bwd) f += L * C + H * DD + (size_t)L * H + C;
+  return f * sizeof(float);
+}
+
+template <int D, bool BWD>
+int small_launch(const SmallArgs& a, int B, hipStream_t st) {
+  const size_t lds = small_lds(a.L, a.S, a.H, D, BWD);
+  static OppLdsOnce once;
+  opp_lds_opt_in(reinterpret_cast<const void*>(la_small_kernel<D, BWD>), 160 * 1024, once);
+  hipLaunchKernelGGL((la_small_kernel<D, BWD>), dim3(B), dim3(a.H * 32), lds, st, a);
+  OPP_CHECK_LAUNCH("la_small_kernel");
+  return OPP_OK;
+}
+
 struct Plan {
   int cq, cs;
   size_t off_pm, off_pv, total;    // floats
@@ -244,6 +405,10 @@ int fwd_impl(const float* q, const float* k, const float* v, const float* qm, co
              float* kv, float* ks, float* ws, hipStream_t st) {
   const Plan p = make_plan(B, L, S, H, D);
   const float inv_s = 1.0f / (float)S, s_len = (float)S;
+  if (small_ok(L, S, H, D) && small_lds(L, S, H, D, false) <= 150 * 1024) {      // short segments: one workgroup per sample, one launch
+    SmallArgs a{q, k, v, qm, km, nullptr, nullptr, nullptr, out, kv, ks, nullptr, nullptr, nullptr, L, S, H, inv_s, s_len, eps};
+    return small_launch<D, false>(a, B, st);
+  }
   hipLaunchKernelGGL((la_outer_kernel<D, 0>), dim3(p.cs, H, B), dim3(kThreads), 0, st, k, v, km, (const float*)nullptr, (const float*)nullptr, S, H,
                      inv_s, s_len, eps, ws + p.off_pm, ws + p.off_pv);
   const size_t nbh = (size_t)B * H;
@@ -260,6 +425,10 @@ int bwd_impl(const float* q, const float* k, const float* v, const float* qm, co
   const Plan p = make_plan(B, L, S, H, D);
   const float inv_s = 1.0f / (float)S, s_len = (float)S;
   const size_t nbh = (size_t)B * H;
+  if (small_ok(L, S, H, D) && small_lds(L, S, H, D, true) <= 150 * 1024) {
+    SmallArgs a{q, k, v, qm, km, kv, ks, g, nullptr, nullptr, nullptr, gq, gk, gv, L, S, H, inv_s, s_len, eps};
+    return small_launch<D, true>(a, B, st);
+  }
   float* gkv = ws + p.total;                    // [B][H][D][D] + [B][H][D] behind the partials
   float* gks = gkv + nbh * D * D;
   hipLaunchKernelGGL((la_outer_kernel<D, 1>), dim3(p.cq, H, B), dim3(kThreads), 0, st, q, g, qm, kv, ks, L, H, inv_s, s_len, eps, ws + p.off_pm,

@@ -451,7 +451,9 @@ def test_linear_backward_vs_fp64(M, K, N, prec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,L,S,H,D,masked", [(2, 96, 77, 8, 32, False), (1, 4096, 5000, 8, 32, True), (3, 25, 1, 8, 16, False),
-                                               (4, 1, 25, 8, 16, False), (2, 130, 64, 8, 32, True)])
+                                               (4, 1, 25, 8, 16, False), (2, 130, 64, 8, 32, True),
+                                               # short segments (L, S <= 32): one workgroup per sample, one launch per pass (la_small_kernel)
+                                               (5, 25, 25, 8, 16, True), (2, 7, 30, 8, 32, True), (1500, 25, 1, 8, 16, False), (3, 32, 32, 4, 32, False)])
 def test_linear_attention_backward_vs_fp64(B, L, S, H, D, masked):
     """LinearAttention.forward with its backward in libopp_hip.so (csrc/linattn_train.hip; the node the training step's graph uses
     instead of three einsums, loftr_module/linear_attention.py:29-61) against torch autograd on an fp64 evaluation of the
