@@ -513,11 +513,20 @@ class HipCoarseMatch(torch.autograd.Function):
             _lib.check(lib.opp_dual_softmax_backward(gc.data_ptr(), sim.data_ptr(), lse_row.data_ptr(), lse_col.data_ptr(), B, N, L, ds.data_ptr(),
                                                      ws.data_ptr(), nb, stream), "opp_dual_softmax_backward")
             ds.mul_(ctx.scale)
+            # sim_b = f3_b f2_b^T is a Linear with x = f3_b, W = f2_b.  The GEMM wants the cell count in multiples of 32: other image sizes
+            # (L = H/8 * W/8) get zero cells appended, which changes neither gradient
+            Lp = (L + 31) // 32 * 32
+            if Lp != L:
+                ds = torch.nn.functional.pad(ds, (0, Lp - L))
+                f2 = torch.nn.functional.pad(f2, (0, 0, 0, Lp - L))
+                nb2 = lib.opp_linear_backward_workspace_bytes(N, Lp, C, hp)
+                if nb2 > nb:
+                    nb, ws = nb2, torch.empty(nb2, dtype=torch.uint8, device=dev)
             g3, g2 = torch.empty_like(f3), torch.empty_like(f2)
-            for b in range(B):                                          # sim_b = f3_b f2_b^T: a Linear with x = f3_b, W = f2_b
-                _lib.check(lib.opp_linear_backward(ds[b].data_ptr(), f3[b].data_ptr(), f2[b].data_ptr(), N, L, C, g3[b].data_ptr(), g2[b].data_ptr(),
+            for b in range(B):
+                _lib.check(lib.opp_linear_backward(ds[b].data_ptr(), f3[b].data_ptr(), f2[b].data_ptr(), N, Lp, C, g3[b].data_ptr(), g2[b].data_ptr(),
                                                    0, hp, ws.data_ptr(), nb, stream), "opp_linear_backward")
-        return g3, g2, None
+        return g3, g2[:, :L], None
 
 
 class HipFineGather(torch.autograd.Function):

@@ -468,3 +468,51 @@ def test_training_graph_matches_the_fused_train_forward(precision, fine, with_ma
         assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, name
         n += 1
     assert n > 100
+
+
+def test_training_graph_vs_torch_autograd_at_an_odd_size():
+    """Whole training graph at a shape no fixture covers -- 104 x 40 image (L = 13 x 5 = 65 cells: not a multiple of 32, which the
+    matcher's backward pads), N = 77 points, B = 2: conf_matrix / expec_f and every parameter gradient of the HIP nodes against
+    torch.autograd of the functional restatement `differentiable_forward` evaluated ON THE DEVICE with plain torch operators (a
+    checker here, never the product).  1e-2 of each tensor's largest entry: two fp32 evaluations may take different sides of a ReLU
+    kink (see test_backbone_node_vs_autograd)."""
+    from onepose_plus_plus_amd import train_autograd as TA
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_inputs, make_state_dict
+    from tests import hip_ops as ops
+    cfg = default_config(thr=0.0)
+    cfg["coarse_matching"]["train"] = {"train_padding": True, "train_coarse_percent": 0.3, "train_pad_num_gt_min": 5}
+    sd = make_state_dict(cfg, 7)
+    hw, n, B = (104, 40), 77, 2
+    parts = [make_inputs(n, hw, 40 + b) for b in range(B)]
+    data = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    L = (hw[0] // 8) * (hw[1] // 8)
+    g = torch.Generator().manual_seed(2)
+    gt = torch.zeros(B, n, L, dtype=torch.int16)
+    for b in range(B):
+        gt[b, torch.randperm(n, generator=g)[:20], torch.randperm(L, generator=g)[:20]] = 1
+    data["conf_matrix_gt"] = gt
+    model = ops.make_model(cfg, sd)
+    model.train()
+    model.train_randint = lambda high, size, device=None, **kw: (torch.arange(size[0]) * 7 % high).to(device)
+    d = {k: v.cuda() for k, v in data.items()}
+    model(d)
+    wc = torch.rand(d["conf_matrix"].shape, generator=g).cuda()
+    we = torch.randn(d["expec_f"].shape, generator=g).cuda()
+    ((d["conf_matrix"] * wc).sum() + (d["expec_f"] * we).sum()).backward()
+    got = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    # the checker: same parameters, same matches, torch operators on the device
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    inputs = {k: d[k] for k in ("query_image", "keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    inputs["query_image_mask"] = None
+    pe = model.dense_pos_encoding.pe.cuda()
+    conf, expec = TA.differentiable_forward(p, cfg, inputs, (d["b_ids"], d["i_ids"], d["j_ids"]), pe)
+    assert float((conf - d["conf_matrix"]).abs().max()) < 2e-5 and float((expec - d["expec_f"]).abs()[:, :2].max()) < 1e-4
+    ((conf * wc).sum() + (expec * we).sum()).backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k, v in p.items():
+        err = float((got[k] - v.grad).abs().max())
+        if err > 1e-2 * float(v.grad.abs().max()) + 1e-9:
+            bad.append((k, err / float(v.grad.abs().max())))
+    assert len(got) == 144 and not bad, sorted(bad, key=lambda t: -t[1])[:6]
