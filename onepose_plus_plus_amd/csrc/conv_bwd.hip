@@ -27,6 +27,8 @@
 //     then dRaw = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); the activation derivative (ReLU / LeakyReLU from
 //     the sign of the saved output) and the residual branch's gradient (dz itself) are formed in the same passes.
 //   bilinear x2 upsample   transposed gather with the forward's own tap arithmetic (upsample2x_backward_kernel).
+#include <stdlib.h>
+
 #include "opp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,6 +54,7 @@ struct WgradArgs {
   int splits = 1, chunks_per_split = 0;
   float* part = nullptr;       // [splits][T][128][128], T = ks*ks*n_ci_tiles*n_co_tiles
   unsigned dy_bytes = 0, x_bytes = 0;
+  int ablate = 0;              // tuning (OPP_WGRAD_ABLATE): 1 no split arithmetic, 2 no global loads, 3 no MFMAs, 4 no LDS hand-over -- wrong results
 };
 
 __device__ __forceinline__ unsigned b3_lvl(float a, float b, float& ra, float& rb) {
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     }
   };
   auto issue_loads = [&](int c) {
+    if (a.ablate == 2) return;
     const int p0 = (c_begin + c) * 32 + pg * 8;
     const bool live = ch_ok && c < n;
 #pragma unroll
@@ -129,6 +133,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
   };
   // registers -> LDS: per channel e the 8 pixels as [hi x8 | mid x8 | lo x8] (48 bytes) into row e * 32 + cq, pixel group pg
   auto split_store = [&](int buf) {
+    if (a.ablate == 4) return;
     float* base = smem + buf * kBuf + (which * 128 + cq) * kS + pg * 12;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -139,6 +144,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float r0, r1, s0, s1, u0, u1;
+        if (a.ablate == 1) {
+          hi[k] = __float_as_uint(x[2 * k]);
+          mid[k] = __float_as_uint(x[2 * k + 1]);
+          lo[k] = hi[k];
+          continue;
+        }
         hi[k] = b3_lvl(x[2 * k], x[2 * k + 1], r0, r1);
         mid[k] = b3_lvl(r0, r1, s0, s1);
         lo[k] = b3_lvl(s0, s1, u0, u1);
@@ -170,6 +181,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
         fa[p] = *reinterpret_cast<const float4*>(As + st * 24 + p * 4);
         fb[0][p] = *reinterpret_cast<const float4*>(Bs + st * 24 + p * 4);
         fb[1][p] = *reinterpret_cast<const float4*>(Bs + 32 * kS + st * 24 + p * 4);
+      }
+      if (a.ablate == 3) {
+        acc[0][0] += fa[0].x + fb[0][1].y + fb[1][2].z;
+        continue;
       }
 #pragma unroll
       for (int pr = 0; pr < 6; ++pr)
@@ -525,6 +540,10 @@ int opp_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, size_t x_p
   plan_splits(T, opp_cdiv(P, 32), a.splits, a.chunks_per_split);
   OPP_CHECK_ARG(ws_bytes >= (size_t)a.splits * T * 16384 * sizeof(float), "conv_wgrad: workspace too small");
   a.part = static_cast<float*>(ws);
+  {
+    static const int abl_env = getenv("OPP_WGRAD_ABLATE") ? atoi(getenv("OPP_WGRAD_ABLATE")) : 0;
+    a.ablate = abl_env;
+  }
   a.dy_bytes = (unsigned)((size_t)P * ldy * 4);
   a.x_bytes = (unsigned)(x_pixels * ldx * 4);
   const size_t lds = (size_t)2 * kBuf * sizeof(float);
