@@ -25,6 +25,9 @@ SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "
            "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "version.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source extras.  conv_bwd.hip: the SLP vectorizer pairs the residual subtractions of the bf16 split into v_pk_add_f32, which
+# costs more beside MFMAs than the two scalar adds it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+SOURCE_FLAGS = {"conv_bwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -73,7 +76,7 @@ def _build(force, verbose, OBJ, LIB, FLAGS):
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        extra = []
+        extra = list(SOURCE_FLAGS.get(src, []))
         if src == "version.hip":
             extra = ['-DOPP_SRC_HASH="%s"' % digest]
             if old != digest:                      # any source changed: the hash baked into this object changes with it

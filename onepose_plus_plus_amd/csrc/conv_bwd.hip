@@ -42,6 +42,7 @@ namespace {
 constexpr unsigned kOob = 0x80000000u;
 constexpr int kS = 52;                 // floats per LDS row and 32-pixel chunk (48 + 4 pad, as gemm_mfma.hip)
 constexpr int kBuf = 256 * kS;         // floats per LDS buffer: rows 0..127 = dY channels, 128..255 = X channels
+constexpr int kDepth = 3;              // chunks of global loads in flight per thread (register sets)
 
 struct WgradArgs {
   const float* dY = nullptr;   // [P][ldy]
@@ -54,7 +55,6 @@ struct WgradArgs {
   int splits = 1, chunks_per_split = 0;
   float* part = nullptr;       // [splits][T][128][128], T = ks*ks*n_ci_tiles*n_co_tiles
   unsigned dy_bytes = 0, x_bytes = 0;
-  int ablate = 0;              // tuning (OPP_WGRAD_ABLATE): 1 no split arithmetic, 2 no global loads, 3 no MFMAs, 4 no LDS hand-over -- wrong results
 };
 
 __device__ __forceinline__ unsigned b3_lvl(float a, float b, float& ra, float& rb) {
@@ -65,13 +65,20 @@ __device__ __forceinline__ unsigned b3_lvl(float a, float b, float& ra, float& r
   return p;
 }
 
+template <int V>
+struct WInt {
+  static constexpr int value = V;
+};
+
+// ABL: timing-only ablations for tools/wgrad_ablate.sh (results wrong): 1 no split arithmetic, 2 no global loads, 3 no MFMAs,
+// 4 no LDS hand-over, 5 no fragment reads, 6 no barrier in the loop, 7 every chunk re-loads chunk 0 (cache-resident operands)
+template <int ABL>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;         // 4 x 2 waves, 32 (co) x 64 (ci) per wave
-  const int set = wave >> 2;                        // loader half of the workgroup
+  const int wm = wave >> 1, wn = wave & 1;         // MFMA role: 4 x 2 waves, 32 (co) x 64 (ci) per wave
 
   const int taps = a.ks * a.ks;
   const int T = taps * a.n_ci_tiles * a.n_co_tiles;
@@ -88,76 +95,78 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
   const int c_begin = split * a.chunks_per_split;
   const int n = max(0, min(a.chunks_per_split, total_chunks - c_begin));
 
-  // loader role of this thread inside its half: 128 units for the dY rows, 128 for the X rows; a unit = 4 channels x 8 pixels
-  const int lt = tid & 255;
-  const int which = lt >> 7;
-  const int u = lt & 127;
-  const int cq = u & 31, pg = u >> 5;
+  // Loader role.  Per WAVE (scalar registers -- a per-lane buffer descriptor would turn every load into a waterfall loop):
+  // the operand (waves 0-3 dY rows, 4-7 X rows) and the 8-pixel group pg of the 32-pixel chunk.  Per lane: 4 channels (cq)
+  // and one half (ph) of the group: 4 pixels x 4 channels = four 16-byte loads and 8 pair conversions per chunk, the same for
+  // every wave, so the body below has no roles and no branches.
+  const int which = wave >> 2;
+  const int pg = wave & 3;
+  const int cq = (lane & 7) + 8 * (lane >> 4);      // a ds_write_b64 is served in groups of 16 contiguous lanes over 32 banks:
+  const int ph = (lane >> 3) & 1;                   // 8 rows (52-float stride: 8 distinct bank quads) x 2 halves fill them
   const int ch0 = (which == 0 ? co_tile : ci_tile) * 128 + cq * 4;
   const int ld = which == 0 ? a.ldy : a.ldx;
   const bool ch_ok = ch0 < ld;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(which == 0 ? a.dY : a.X), 0,
                                                                       which == 0 ? a.dy_bytes : a.x_bytes, 0x00020000);
-  int2 geo[8] = {};   // geometry of the chunk this thread loads next (X rows with a table only)
-  float4 v[8];        // its loaded values: pixel j, channels ch0 .. ch0 + 3
   const bool use_geo = (which == 1) && (a.geo != nullptr);
+  // geometry through a descriptor of its own: 0 records when there is no table (every fetch returns 0, no branch)
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int2*>(use_geo ? a.geo : nullptr), 0,
+                                                                       use_geo ? (unsigned)(((size_t)total_chunks * 32) * 8) : 0u, 0x00020000);
+  u32x4 geo[2][2] = {};   // [set][half]: {origin, mask} of this lane's 4 pixels, two chunks' worth in flight
+  float4 v[kDepth][4];    // kDepth chunks of loaded values in flight: [set][pixel], channels ch0 .. ch0 + 3
 
-  auto load_geo = [&](int c) {       // c = chunk index inside this split
-    if (use_geo && c < n) {
-      const int4* gp = reinterpret_cast<const int4*>(a.geo + (size_t)(c_begin + c) * 32 + pg * 8);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int4 g4 = gp[q];
-        geo[2 * q] = make_int2(g4.x, g4.y);
-        geo[2 * q + 1] = make_int2(g4.z, g4.w);
-      }
-    }
+  auto load_geo = [&](int c, u32x4 (&g)[2]) {       // c = chunk index inside this split
+    const int e0 = ((ABL == 7 ? 0 : (c_begin + c) * 32) + pg * 8 + ph * 4) * 8;
+    g[0] = __builtin_amdgcn_raw_buffer_load_b128(grs, e0, 0, 0);
+    g[1] = __builtin_amdgcn_raw_buffer_load_b128(grs, e0 + 16, 0, 0);
   };
-  auto issue_loads = [&](int c) {
-    if (a.ablate == 2) return;
-    const int p0 = (c_begin + c) * 32 + pg * 8;
-    const bool live = ch_ok && c < n;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      unsigned off;
-      if (use_geo) {
-        const bool ok = live && ((((unsigned)geo[j].y) >> tap) & 1u);
-        off = ok ? (unsigned)((geo[j].x + tap_off) * ld + ch0) * 4u : kOob;
+  auto issue_load = [&](int c, int j, const u32x4 (&g)[2], float4& dst) {
+    const int p = (ABL == 7 ? 0 : (c_begin + c) * 32) + pg * 8 + ph * 4 + j;
+    const unsigned gx = j == 0 ? g[0].x : j == 1 ? g[0].z : j == 2 ? g[1].x : g[1].z;
+    const unsigned gm = j == 0 ? g[0].y : j == 1 ? g[0].w : j == 2 ? g[1].y : g[1].w;
+    const int pix = use_geo ? (int)gx + tap_off : p;                       // bitwise, not &&: no branches in the chunk body
+    const unsigned ok = (unsigned)ch_ok & (unsigned)(c < n) & (use_geo ? (gm >> tap) & 1u : (unsigned)(p < a.P));
+    const unsigned o = (unsigned)(pix * ld + ch0) * 4u;
+    if (ABL == 2) return;
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? o : kOob), 0, 0);
+    dst = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+  };
+  // registers -> LDS in 24 steps (one per MFMA slot).  Step t = 3 * unit + level; unit = (channel e, pixel pair k) of this lane's
+  // 4 channels x 4 pixels; level 0 / 1 / 2 peels the bf16 hi / mid / lo pair off the two values (exact: 3 x 8 significand bits).
+  // After a channel's last step its three 8-byte pieces go into row e * 32 + cq at [hi x8 | mid x8 | lo x8] + this lane's half
+  // (conflict-free: see cq / ph above).
+  float* const wbase = smem + (which * 128 + cq) * kS + pg * 12 + ph * 2;
+  unsigned hi[2], mid[2], lo[2];
+  float cr0 = 0.f, cr1 = 0.f;   // residuals carried from one level to the next
+  auto convert_step = [&](int t, const float4 (&src)[4], int buf) {
+    const int unit = t / 3, lvl = t - 3 * unit;
+    const int e = unit >> 1, k = unit & 1;
+    if (ABL == 4) return;
+    if (lvl == 0) {
+      const float4& p0 = src[2 * k];
+      const float4& p1 = src[2 * k + 1];
+      const float x0 = e == 0 ? p0.x : e == 1 ? p0.y : e == 2 ? p0.z : p0.w;
+      const float x1 = e == 0 ? p1.x : e == 1 ? p1.y : e == 2 ? p1.z : p1.w;
+      if (ABL == 1) {
+        hi[k] = __float_as_uint(x0);
+        mid[k] = __float_as_uint(x1);
+        lo[k] = hi[k];
       } else {
-        const int p = p0 + j;
-        off = (live && p < a.P) ? (unsigned)(p * ld + ch0) * 4u : kOob;
+        hi[k] = b3_lvl(x0, x1, cr0, cr1);
       }
-      const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
-      v[j] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
-    }
-  };
-  // registers -> LDS: per channel e the 8 pixels as [hi x8 | mid x8 | lo x8] (48 bytes) into row e * 32 + cq, pixel group pg
-  auto split_store = [&](int buf) {
-    if (a.ablate == 4) return;
-    float* base = smem + buf * kBuf + (which * 128 + cq) * kS + pg * 12;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = e == 0 ? v[j].x : e == 1 ? v[j].y : e == 2 ? v[j].z : v[j].w;
-      unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float r0, r1, s0, s1, u0, u1;
-        if (a.ablate == 1) {
-          hi[k] = __float_as_uint(x[2 * k]);
-          mid[k] = __float_as_uint(x[2 * k + 1]);
-          lo[k] = hi[k];
-          continue;
-        }
-        hi[k] = b3_lvl(x[2 * k], x[2 * k + 1], r0, r1);
-        mid[k] = b3_lvl(r0, r1, s0, s1);
-        lo[k] = b3_lvl(s0, s1, u0, u1);
+    } else if (lvl == 1) {
+      if (ABL != 1) mid[k] = b3_lvl(cr0, cr1, cr0, cr1);
+    } else {
+      if (ABL != 1) {
+        float u0, u1;
+        lo[k] = b3_lvl(cr0, cr1, u0, u1);
       }
-      float* row = base + e * 32 * kS;
-      *reinterpret_cast<uint4*>(row) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-      *reinterpret_cast<uint4*>(row + 4) = make_uint4(mid[0], mid[1], mid[2], mid[3]);
-      *reinterpret_cast<uint4*>(row + 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+      if (k == 1) {
+        float* row = wbase + buf * kBuf + e * 32 * kS;
+        *reinterpret_cast<uint2*>(row) = make_uint2(hi[0], hi[1]);
+        *reinterpret_cast<uint2*>(row + 4) = make_uint2(mid[0], mid[1]);
+        *reinterpret_cast<uint2*>(row + 8) = make_uint2(lo[0], lo[1]);
+      }
     }
   };
 
@@ -167,53 +176,92 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+  // fragments of the two k16-steps of a chunk: [hi, mid, lo] of the wave's 32 dY rows and of its two 32-row X blocks
+  float4 f0a[3], f0b[2][3], f1a[3], f1b[2][3];
+  const float* const a_frag = smem + (wm * 32 + l31) * kS + half * 12;
+  const float* const b_frag = smem + (128 + wn * 64 + l31) * kS + half * 12;
+  auto read_frags = [&](int buf, int st, float4 (&fa)[3], float4 (&fb)[2][3]) {
+    const float* As = a_frag + buf * kBuf + st * 24;
+    const float* Bs = b_frag + buf * kBuf + st * 24;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      fa[p] = *reinterpret_cast<const float4*>(As + p * 4);
+      fb[0][p] = *reinterpret_cast<const float4*>(Bs + p * 4);
+      fb[1][p] = *reinterpret_cast<const float4*>(Bs + 32 * kS + p * 4);
+    }
+  };
   auto as_b8 = [](const float4& f) { return *reinterpret_cast<const bf16x8*>(&f); };
-  auto mfma_chunk = [&](int buf) {
-    const float* As = smem + buf * kBuf + (wm * 32 + l31) * kS + half * 12;
-    const float* Bs = smem + buf * kBuf + (128 + wn * 64 + l31) * kS + half * 12;
+  // MFMAs first .. last - 1 of a k16-step (12 = 6 products x 2 column blocks), `between(i)` after the i-th: the slot in which
+  // this wave's other work is issued while the matrix pipe runs
+  auto mfma_range = [&](const float4 (&fa)[3], const float4 (&fb)[2][3], int first, int last, auto&& between) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};      // lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi: smallest terms first
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      float4 fa[3], fb[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        fa[p] = *reinterpret_cast<const float4*>(As + st * 24 + p * 4);
-        fb[0][p] = *reinterpret_cast<const float4*>(Bs + st * 24 + p * 4);
-        fb[1][p] = *reinterpret_cast<const float4*>(Bs + 32 * kS + st * 24 + p * 4);
-      }
-      if (a.ablate == 3) {
-        acc[0][0] += fa[0].x + fb[0][1].y + fb[1][2].z;
-        continue;
-      }
-#pragma unroll
-      for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[PA[pr]]), as_b8(fb[j][PB[pr]]), acc[j], 0, 0, 0);
+    for (int i = first; i < last; ++i) {
+      const int pr = i >> 1, j = i & 1;
+      if (ABL == 3) acc[j][i] += fa[PA[pr]].x + fb[j][PB[pr]].y;
+      else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[PA[pr]]), as_b8(fb[j][PB[pr]]), acc[j], 0, 0, 0);
+      between(i);
     }
   };
 
-  // chunk c is handed to LDS by loader half (c & 1).  Prologue: half 0 brings chunk 0 in, half 1 has chunk 1 in flight.
-  if (set == 0) {
-    load_geo(0);
-    issue_loads(0);
-    split_store(0);
-    load_geo(2);
-  } else {
-    load_geo(1);
-    issue_loads(1);
+  // Prologue: chunks 0 and 1 handed to LDS buffers 0 and 1, chunks 2 and 3 in flight, the geometry of chunks 4 and 5 on its way,
+  // k16-step 0 of chunk 0 done.
+#pragma unroll
+  for (int d = 0; d < kDepth; ++d) {
+    load_geo(d, geo[d & 1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_load(d, j, geo[d & 1], v[d][j]);
   }
+#pragma unroll
+  for (int t = 0; t < 24; ++t) convert_step(t, v[0], 0);
+  load_geo(3, geo[1]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) issue_load(3, j, geo[1], v[0][j]);
+#pragma unroll
+  for (int t = 0; t < 24; ++t) convert_step(t, v[1], 1);
+  load_geo(4, geo[0]);
+  load_geo(5, geo[1]);
   __syncthreads();
-  for (int c = 0; c < n; ++c) {
-    if (set == ((c + 1) & 1)) {          // my chunk c + 1 is in registers: convert it while the other half runs MFMAs
-      if (c + 1 < n) split_store((c + 1) & 1);
-      load_geo(c + 3);
-    } else {                             // my chunk c + 2: put its loads in flight under this chunk's MFMAs
-      issue_loads(c + 2);
-    }
-    mfma_chunk(c & 1);
-    __syncthreads();
+  read_frags(0, 0, f0a, f0b);
+  read_frags(0, 1, f1a, f1b);
+  mfma_range(f0a, f0b, 0, 12, [](int) {});
+
+  // One interval = from the barrier of chunk c to the barrier of chunk c + 1; K = c % 6 at compile time gives the LDS buffer
+  // (K & 1) and the register sets.  At the barrier every wave has ALL fragments of chunk c (buffer P) in registers and buffer
+  // P ^ 1 (chunk c + 1) is complete, so between two barriers
+  //   the matrix pipe runs k16-step 1 of chunk c, then k16-step 0 of chunk c + 1 -- 24 MFMAs whose operands were read from LDS
+  //     half an interval earlier: no LDS latency and no load on either side of the barrier;
+  //   the 24 slots behind those MFMAs carry, evenly, the conversion of chunk c + 2 (in registers since two intervals) into
+  //     buffer P, which nobody reads any more, the four loads of chunk c + 4 and the geometry of chunk c + 6.
+  // Neither the body nor the loop around six of them has a branch: the waitcnt pass counts the loads in flight instead of
+  // draining them and nothing is sunk out of its slot into a successor block.  A chunk index past the end loads zeros
+  // (out-of-range offsets): the host makes chunks_per_split a multiple of 6.
+  auto interval = [&](auto kk, int c) {
+    constexpr int K = decltype(kk)::value;
+    constexpr int P = K & 1, CONV = (K + 2) % kDepth, LOAD = (K + 4) % kDepth, G = K & 1;
+    if (ABL != 6) __syncthreads();
+    if (ABL != 5) read_frags(P ^ 1, 0, f0a, f0b);
+    __builtin_amdgcn_sched_barrier(0);
+    auto slot = [&](int t) {
+      convert_step(t, v[CONV], P);
+      if (t % 6 == 2) issue_load(c + 4, t / 6, geo[G], v[LOAD][t / 6]);
+      if (t == 21) load_geo(c + 6, geo[G]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    mfma_range(f1a, f1b, 0, 12, [&](int i) { slot(i); });
+    if (ABL != 5) read_frags(P ^ 1, 1, f1a, f1b);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_range(f0a, f0b, 0, 12, [&](int i) { slot(12 + i); });
+  };
+  static_assert(kDepth == 3, "the six-interval body below is lcm(2 LDS buffers, kDepth register sets)");
+  for (int c = 0; c < n; c += 6) {
+    interval(WInt<0>{}, c);
+    interval(WInt<1>{}, c + 1);
+    interval(WInt<2>{}, c + 2);
+    interval(WInt<3>{}, c + 3);
+    interval(WInt<4>{}, c + 4);
+    interval(WInt<5>{}, c + 5);
   }
 
   // partial tile in the PERMUTED row / column order (lanes along columns: 128-byte stores); conv_wgrad_reduce_kernel un-permutes
@@ -483,21 +531,24 @@ int grid_for(size_t total, int block = 256, int cap = 16384) {
 }
 
 // splits of the pixel range: a multiple of 8 (one XCD per split) minimising rounds x (chunks per split + fixed cost)
+// chunks per split (a multiple of the kernel's six-chunk body) and number of splits.  The T workgroups of a split sit on ONE XCD
+// (32 CUs, one workgroup each: 106 KB of LDS), split k on XCD k % 8: cost = rounds of 32 workgroups on the fullest XCD times the
+// length of one workgroup (+ 8 chunk-times of prologue, epilogue and reduce).
 void plan_splits(int T, int total_chunks, int& splits, int& cps) {
   long long best = -1;
-  int best_s = 8;
-  for (int s = 8; s <= 512; s += 8) {
-    const int c = opp_cdiv(total_chunks, s);
-    if (c < 4 && s > 8) break;
-    const long long blocks = (long long)s * T;
-    const long long rounds = (blocks + 255) / 256;
+  int best_c = 6;
+  for (int c = 6; c <= 6 * 4096; c += 6) {
+    const int s = opp_cdiv(total_chunks, c);
+    if (s > 512) continue;
+    const long long rounds = ((long long)opp_cdiv(s, 8) * T + 31) / 32;
     const long long cost = rounds * (c + 8);
     if (best < 0 || cost < best) {
       best = cost;
-      best_s = s;
+      best_c = c;
     }
+    if (s == 1) break;
   }
-  cps = opp_cdiv(total_chunks, best_s);
+  cps = best_c;
   splits = opp_cdiv(total_chunks, cps);
 }
 
@@ -540,19 +591,35 @@ int opp_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, size_t x_p
   plan_splits(T, opp_cdiv(P, 32), a.splits, a.chunks_per_split);
   OPP_CHECK_ARG(ws_bytes >= (size_t)a.splits * T * 16384 * sizeof(float), "conv_wgrad: workspace too small");
   a.part = static_cast<float*>(ws);
-  {
-    static const int abl_env = getenv("OPP_WGRAD_ABLATE") ? atoi(getenv("OPP_WGRAD_ABLATE")) : 0;
-    a.ablate = abl_env;
-  }
   a.dy_bytes = (unsigned)((size_t)P * ldy * 4);
   a.x_bytes = (unsigned)(x_pixels * ldx * 4);
   const size_t lds = (size_t)2 * kBuf * sizeof(float);
   static OppLdsOnce lds_once;
-  opp_lds_opt_in(reinterpret_cast<const void*>(conv_wgrad_kernel), lds, lds_once);
+  opp_lds_opt_in(reinterpret_cast<const void*>(conv_wgrad_kernel<0>), lds, lds_once);
   const int blocks = opp_cdiv(a.splits, 8) * 8 * T;
+#ifdef OPP_TUNING
+  static const int abl = getenv("OPP_WGRAD_ABLATE") ? atoi(getenv("OPP_WGRAD_ABLATE")) : 0;
+  if (abl >= 1 && abl <= 7) {
+    static OppLdsOnce abl_once[8];
+    auto go = [&](auto k, int i) {
+      opp_lds_opt_in(reinterpret_cast<const void*>(k), lds, abl_once[i]);
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(512), lds, stream, a);
+    };
+    switch (abl) {
+      case 1: go(conv_wgrad_kernel<1>, 1); break;
+      case 2: go(conv_wgrad_kernel<2>, 2); break;
+      case 3: go(conv_wgrad_kernel<3>, 3); break;
+      case 4: go(conv_wgrad_kernel<4>, 4); break;
+      case 5: go(conv_wgrad_kernel<5>, 5); break;
+      case 6: go(conv_wgrad_kernel<6>, 6); break;
+      default: go(conv_wgrad_kernel<7>, 7); break;
+    }
+    return OPP_OK;
+  }
+#endif
   {
     OppProfScope prof(OPP_PROF_CONV_WGRAD, stream, 2.0 * (double)P * cout * cin * ks * ks);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(blocks), dim3(512), lds, stream, a);
   }
   OPP_CHECK_LAUNCH("conv_wgrad_kernel");
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid_for((size_t)T * 16384)), dim3(256), 0, stream, a.part, a.splits, ks * ks, a.n_ci_tiles,

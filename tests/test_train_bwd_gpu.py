@@ -107,7 +107,8 @@ def test_conv_wgrad_long_reduction():
                                             ws.data_ptr(), nb, _s()), "opp_conv2d_backward_nhwc")
     torch.cuda.synchronize()
     # error relative to sum |a||b| ~ sqrt(P) * 0.64: a few fp32 ulps of the largest partial sums
-    assert float((gw.cpu().double() - wd.grad).abs().max()) < 3e-6 * (B * H * W) ** 0.5
+    err = float((gw.cpu().double() - wd.grad).abs().max())
+    assert err < 5e-6 * (B * H * W) ** 0.5, err
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])

@@ -1,6 +1,6 @@
 """Stand-alone timing of the convolution backward kernels at the training step's shapes (B = 4, 512 x 512 images):
 input gradient (implicit-GEMM kernel on the flipped weight) and weight gradient (conv_wgrad_kernel), TFLOP/s of the
-algorithmic 2 * P * cout * cin * k * k each.     python tools/conv_bwd_bench.py [B]"""
+algorithmic 2 * P * cout * cin * k * k each.     python tools/conv_bwd_bench.py [B] [--only <substring of the shape name>] [--what dgrad|wgrad] [--iters N]"""
 import os
 import sys
 
@@ -24,11 +24,17 @@ SHAPES = [  # name, cin, cout, ks, stride, Hin (= Win)
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    argv = sys.argv[1:]
+    only = argv[argv.index("--only") + 1] if "--only" in argv else ""
+    what_only = argv[argv.index("--what") + 1] if "--what" in argv else ""
+    iters = int(argv[argv.index("--iters") + 1]) if "--iters" in argv else 200
+    B = int(argv[0]) if argv and not argv[0].startswith("--") else 4
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
     pad = lambda c: (c + 31) // 32 * 32
     for name, cin, cout, ks, stride, H in SHAPES:
+        if only and only not in name:
+            continue
         Ho = H // stride
         x = torch.randn(B, H, H, pad(cin), device="cuda")
         gy = torch.randn(B, Ho, Ho, pad(cout), device="cuda")
@@ -41,15 +47,18 @@ def main():
         flops = 2.0 * B * Ho * Ho * cout * cin * ks * ks
         res = []
         for what, a, b in (("dgrad", gx, None), ("wgrad", None, gw)):
+            if what_only and what != what_only:
+                continue
+
             def run():
                 _lib.check(lib.opp_conv2d_backward_nhwc(x.data_ptr(), B, H, H, cin, w.data_ptr(), cout, ks, stride, gy.data_ptr(),
                                                         a.data_ptr() if a is not None else None, None, b.data_ptr() if b is not None else None, 2,
                                                         ws.data_ptr(), nb, s), "conv2d_backward")
-            for _ in range(2):
+            for _ in range(max(2, iters // 4)):     # the clock settles over tens of milliseconds: warm up with real work
                 run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 5
+            n = iters
             e0.record()
             for _ in range(n):
                 run()
