@@ -27,7 +27,7 @@ HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source extras.  conv_bwd.hip: the SLP vectorizer pairs the residual subtractions of the bf16 split into v_pk_add_f32, which
 # costs more beside MFMAs than the two scalar adds it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
-SOURCE_FLAGS = {"conv_bwd.hip": ["-fno-slp-vectorize"]}
+SOURCE_FLAGS = {"conv_bwd.hip": ["-fno-slp-vectorize"], "gemm_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -58,14 +58,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, tuning=False):
-    obj_dir = OBJ + ("_tuning" if tuning else "")
-    lib_path = LIB.replace(".so", "_tuning.so") if tuning else LIB
+def build(force=False, verbose=True, tuning=False, variant=None):
+    """variant: A/B builds for tools/ (libopp_hip_<variant>.so): "slp" = every source with the SLP vectorizer left on"""
+    suffix = "_tuning" if tuning else ("_" + variant if variant else "")
+    obj_dir = OBJ + suffix
+    lib_path = LIB.replace(".so", suffix + ".so")
     flags = FLAGS + (["-DOPP_TUNING"] if tuning else [])
-    return _build(force, verbose, obj_dir, lib_path, flags)
+    return _build(force, verbose, obj_dir, lib_path, flags, {} if variant == "slp" else SOURCE_FLAGS)
 
 
-def _build(force, verbose, OBJ, LIB, FLAGS):
+def _build(force, verbose, OBJ, LIB, FLAGS, SOURCE_FLAGS):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
@@ -110,4 +112,5 @@ def _build(force, verbose, OBJ, LIB, FLAGS):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv,
+                variant=sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None))

@@ -8,18 +8,24 @@
 //   conv weight gradient   dW[co][ci][ky][kx] = sum_p dY[p][co] * X[p shifted by (ky, kx)][ci]        (conv_wgrad_kernel)
 //     a tiny output under a huge reduction over the B*Ho*Wo output pixels.  Both operands are PIXEL-major in memory (NHWC:
 //     channel contiguous) while the MFMA wants 8 consecutive reduction indices per lane, so the loader transposes in
-//     REGISTERS: a thread fetches 4 channels x 8 consecutive pixels (eight 16-byte loads, each coalesced over the channels of
+//     REGISTERS: a lane fetches 4 channels x 4 consecutive pixels (four 16-byte loads, each coalesced over the channels of
 //     one pixel), splits every value exactly into bf16 hi + mid + lo (the bf16x3 arithmetic of gemm_mfma.hip: six
-//     v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, not narrower than fp32) and writes, per channel, the 48-byte
-//     [hi x8 | mid x8 | lo x8] group of those 8 pixels with three ds_write_b128 -- the LDS image is exactly the fragment
-//     layout of opp_gemm_kernel<bf16x3> (52-float rows: conflict-free ds_read_b128), there are no 16-bit scattered stores and
-//     no transposed copies of the activations in memory.  LDS rows are channel-permuted (row = (c % 4) * 32 + c / 4) so that
-//     consecutive lanes write consecutive rows; the permutation is undone when the partial tiles are reduced.
-//     8 waves on a 128 (co) x 128 (ci) tile of ONE tap; the two 4-wave halves of the workgroup alternate as loader of the next
-//     32-pixel chunk (global loads one chunk ahead of the split + LDS hand-over, geometry one more chunk ahead), so that on
-//     every SIMD one wave converts while its partner feeds the matrix pipe.  Split over the pixel range (grid = taps x tiles x
-//     splits, the splits of one pixel range on one XCD so that the nine taps share the range through that L2), partial tiles
-//     reduced in split order in fp64 (deterministic) straight into the PyTorch weight layout.
+//     v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate, not narrower than fp32) and writes, per channel, its half of
+//     the 48-byte [hi x8 | mid x8 | lo x8] group of 8 pixels with three ds_write_b64 -- the LDS image is exactly the fragment
+//     layout of opp_gemm_kernel<bf16x3> (52-float rows: conflict-free ds_read_b128; the lane -> (row, half) map makes the
+//     8-byte stores conflict-free too), there are no 16-bit scattered stores and no transposed copies of the activations in
+//     memory.  LDS rows are channel-permuted (row = (c % 4) * 32 + c / 4) so that consecutive lanes write consecutive rows; the
+//     permutation is undone when the partial tiles are reduced.
+//     8 waves on a 128 (co) x 128 (ci) tile of ONE tap, 32 x 64 per wave.  The loader role is per WAVE (operand and 8-pixel
+//     group in scalar registers: a per-lane buffer descriptor would turn every load into a waterfall loop) and identical for
+//     all waves; the body between two barriers is branch-free: 24 MFMAs whose fragments were read half an interval earlier, and
+//     in the 24 slots behind them the conversion of the chunk two ahead, the loads of the chunk four ahead and the geometry of
+//     the chunk six ahead (three register sets, two LDS buffers, ONE barrier per 32-pixel chunk).  Split over the pixel range
+//     (grid = taps x tiles x splits, the splits of one pixel range on one XCD so that the nine taps share the range through
+//     that L2; the plan counts rounds per XCD), partial tiles reduced in a fixed order in fp64 (deterministic) straight into
+//     the PyTorch weight layout.  Measured (profiles/r04_wgrad_*.txt): 174 TFLOP/s on layer1's shape with the GPU at its
+//     1.3 kW limit (1.95 GHz); every structural variant of the loop lands within 2 % of that, so what is left is energy per
+//     product (six MFMAs, the re-conversion of both operands for each of the nine taps), not scheduling.
 //     The same kernel is the weight gradient of a Linear (a 1 x 1 "convolution" over tokens): opp_wgrad_rows().
 //   conv input gradient    = the forward implicit-GEMM kernel on the flipped / transposed weight (conv_flip_transpose_kernel),
 //     stride 2 through a zero-inserted copy of dY (conv_dilate_kernel)                                    (api.hip drives it)
@@ -275,25 +281,57 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dW[co][ci][tap] (PyTorch [cout][cin][ks][ks]) = sum over the splits, in split order, in fp64
+// dW[co][ci][tap] (PyTorch [cout][cin][ks][ks]) = sum over the splits in fp64 in a FIXED order: a workgroup owns 64 float4 of one
+// partial tile; its four 64-thread groups each sum a contiguous quarter of the splits (in split order), then the quarter sums are
+// added 0 + 1 + 2 + 3 -- the same tree on every run, four times shorter than one chain per output
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int n_ci_tiles,
                                                                 int n_co_tiles, int cout, int cin, float* __restrict__ dW, int accumulate) {
+  __shared__ double sh[3][64][4];
   const int T = taps * n_ci_tiles * n_co_tiles;
-  const size_t total = (size_t)T * 16384;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i >> 14);
-    const int e = (int)(i & 16383);
-    const int row = e >> 7, col = e & 127;
-    const int tap = t % taps;
-    const int rest = t / taps;
-    const int ci_tile = rest % n_ci_tiles, co_tile = rest / n_ci_tiles;
-    const int co = co_tile * 128 + 4 * (row & 31) + (row >> 5);
-    const int ci = ci_tile * 128 + 4 * (col & 31) + (col >> 5);
-    if (co >= cout || ci >= cin) continue;
-    double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += (double)part[((size_t)k * T + t) * 16384 + e];
-    float* o = dW + ((size_t)co * cin + ci) * taps + tap;
-    *o = accumulate ? *o + (float)s : (float)s;
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t e4 = (size_t)blockIdx.x * 64 + o;          // float4 index over [T][4096]
+  const int t = (int)(e4 >> 12);
+  const int e = (int)(e4 & 4095) * 4;                     // first of 4 consecutive columns of one row
+  const int per = (splits + 3) >> 2;
+  const int k0 = q * per, k1 = min(splits, k0 + per);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const float4* src = reinterpret_cast<const float4*>(part) + (size_t)t * 4096 + (e >> 2);
+  for (int k = k0; k < k1; ++k) {
+    const float4 v = src[(size_t)k * T * 4096];
+    s0 += (double)v.x;
+    s1 += (double)v.y;
+    s2 += (double)v.z;
+    s3 += (double)v.w;
+  }
+  if (q > 0) {
+    sh[q - 1][o][0] = s0;
+    sh[q - 1][o][1] = s1;
+    sh[q - 1][o][2] = s2;
+    sh[q - 1][o][3] = s3;
+  }
+  __syncthreads();
+  if (q > 0) return;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    s0 += sh[r][o][0];
+    s1 += sh[r][o][1];
+    s2 += sh[r][o][2];
+    s3 += sh[r][o][3];
+  }
+  const int row = e >> 7, col = e & 127;
+  const int tap = t % taps;
+  const int rest = t / taps;
+  const int ci_tile = rest % n_ci_tiles, co_tile = rest / n_ci_tiles;
+  const int co = co_tile * 128 + 4 * (row & 31) + (row >> 5);
+  if (co >= cout) return;
+  const double sv[4] = {s0, s1, s2, s3};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = col + i;
+    const int ci = ci_tile * 128 + 4 * (c & 31) + (c >> 5);
+    if (ci >= cin) continue;
+    float* dst = dW + ((size_t)co * cin + ci) * taps + tap;
+    *dst = accumulate ? *dst + (float)sv[i] : (float)sv[i];
   }
 }
 
@@ -622,7 +660,7 @@ int opp_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, size_t x_p
     hipLaunchKernelGGL(conv_wgrad_kernel<0>, dim3(blocks), dim3(512), lds, stream, a);
   }
   OPP_CHECK_LAUNCH("conv_wgrad_kernel");
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(grid_for((size_t)T * 16384)), dim3(256), 0, stream, a.part, a.splits, ks * ks, a.n_ci_tiles,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(T * 64), dim3(256), 0, stream, a.part, a.splits, ks * ks, a.n_ci_tiles,
                      a.n_co_tiles, cout, cin, dW, accumulate);
   OPP_CHECK_LAUNCH("conv_wgrad_reduce_kernel");
   return OPP_OK;
