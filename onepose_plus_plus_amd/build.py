@@ -25,8 +25,11 @@ SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "
            "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "version.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-# per-source extras.  conv_bwd.hip: the SLP vectorizer pairs the residual subtractions of the bf16 split into v_pk_add_f32, which
-# costs more beside MFMAs than the two scalar adds it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+# per-source extras.  The two files whose kernels split fp32 values into bf16 triples beside MFMAs: the SLP vectorizer pairs the
+# residual subtractions of the split into v_pk_add_f32, which costs more there than the two scalar adds it replaces
+# (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; +0.4 % images/s, profiles/r04_ab_slp_vectorizer.txt).  The scalar and
+# the packed forms contract into FMAs differently, so arithmetic that two files must round identically (the LayerNorm of the fused
+# encoder chain against the launch-per-Linear path) is written with explicit FMAs (opp_common.h: opp_ln_*), not left to the flags.
 SOURCE_FLAGS = {"conv_bwd.hip": ["-fno-slp-vectorize"], "gemm_mfma.hip": ["-fno-slp-vectorize"]}
 
 
@@ -59,12 +62,15 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True, tuning=False, variant=None):
-    """variant: A/B builds for tools/ (libopp_hip_<variant>.so): "slp" = every source with the SLP vectorizer left on"""
+    """variant: A/B builds for tools/ (libopp_hip_<variant>.so): "slp" = gemm_mfma.hip with the SLP vectorizer left on"""
     suffix = "_tuning" if tuning else ("_" + variant if variant else "")
     obj_dir = OBJ + suffix
     lib_path = LIB.replace(".so", suffix + ".so")
     flags = FLAGS + (["-DOPP_TUNING"] if tuning else [])
-    return _build(force, verbose, obj_dir, lib_path, flags, {} if variant == "slp" else SOURCE_FLAGS)
+    extra = dict(SOURCE_FLAGS)
+    if variant == "slp":
+        extra.pop("gemm_mfma.hip", None)
+    return _build(force, verbose, obj_dir, lib_path, flags, extra)
 
 
 def _build(force, verbose, OBJ, LIB, FLAGS, SOURCE_FLAGS):

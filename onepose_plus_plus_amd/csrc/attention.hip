@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       const float d = v[r][i] - mean[r];
-      sm[r] += d * d;
+      sm[r] = opp_ln_sq_acc(d, sm[r]);
     }
   }
 #pragma unroll
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       vec_t o;
 #pragma unroll
       for (int i = 0; i < VPT; ++i) {
-        float y = (v[r][i] - mean[r]) * rstd[r] * gm[i] + bt[i];
+        float y = opp_ln_affine(v[r][i], mean[r], rstd[r], gm[i], bt[i]);
         if (res) y = rv[r][i] + y;
         o[i] = y;
       }

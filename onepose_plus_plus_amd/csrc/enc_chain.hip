@@ -237,7 +237,7 @@ __global__ __launch_bounds__(C * 2) void enc_chain_kernel(const OppEncChain a) {
 #pragma unroll
       for (int i = 0; i < VPT; ++i) {
         const float d = v[r][i] - mean[r];
-        sm[r] += d * d;
+        sm[r] = opp_ln_sq_acc(d, sm[r]);
       }
     }
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(C * 2) void enc_chain_kernel(const OppEncChain a) {
       const int lr = wave * RPW + r;
       float y[VPT];
 #pragma unroll
-      for (int i = 0; i < VPT; ++i) y[i] = (v[r][i] - mean[r]) * rstd[r] * gmv[i] + btv[i];
+      for (int i = 0; i < VPT; ++i) y[i] = opp_ln_affine(v[r][i], mean[r], rstd[r], gmv[i], btv[i]);
       if constexpr (MODE == 0) {
         // lane owns k = lane * VPT .. + VPT - 1 of the row: VPT / 2 packed dwords per part
         char* g = dst + lr * SA + ((lane * VPT) >> 3) * 48 + ((lane * VPT) & 7) * 2;

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float d = v[r][i] - mean[r];
-        sm[r] += d * d;
+        sm[r] = opp_ln_sq_acc(d, sm[r]);
       }
     }
 #pragma unroll
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
       const int lr = rb + wave * RPW + r;
       float y[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[i] = (v[r][i] - mean[r]) * rstd[r] * gmv[i] + btv[i];
+      for (int i = 0; i < 4; ++i) y[i] = opp_ln_affine(v[r][i], mean[r], rstd[r], gmv[i], btv[i]);
       if constexpr (MODE == 0) {
         char* g = A + lr * SA + ((lane * 4) >> 3) * 48 + ((lane * 4) & 7) * 2;   // lane owns k = 4 lane .. 4 lane + 3
 #pragma unroll

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
             for (int i = 0; i < VPT; ++i) {
               const float d = v[r][i] - mean[r];
-              sm[r] += d * d;
+              sm[r] = opp_ln_sq_acc(d, sm[r]);
             }
           }
 #pragma unroll
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
               vec_t o;
 #pragma unroll
               for (int i = 0; i < VPT; ++i) {
-                float y = (v[r][i] - mean[r]) * rstd[r] * gmv[i] + btv[i];
+                float y = opp_ln_affine(v[r][i], mean[r], rstd[r], gmv[i], btv[i]);
                 if (g.ln_res) y = rv[r][i] + y;
                 o[i] = y;
               }

@@ -182,5 +182,16 @@ __device__ __forceinline__ float opp_wave_sum_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+
+// LayerNorm arithmetic shared by every kernel that normalises a token row (gemm_mfma.hip epilogue, attention.hip, enc_chain.hip,
+// enc_layer64.hip): the fused multiply-adds are EXPLICIT, so the fused encoder chain and the launch-per-Linear
+// path round identically whatever the compiler's contraction / vectorisation choices are in each file.
+#ifdef __HIPCC__
+__device__ __forceinline__ float opp_ln_sq_acc(float d, float acc) { return __builtin_fmaf(d, d, acc); }
+__device__ __forceinline__ float opp_ln_affine(float v, float mean, float rstd, float gm, float bt) {
+  return __builtin_fmaf((v - mean) * rstd, gm, bt);
+}
+#endif
+
 #endif
 

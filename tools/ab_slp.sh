@@ -1,5 +1,5 @@
 # A/B of the SLP vectorizer in gemm_mfma.hip (v_pk_add_f32 beside the MFMAs of the bf16 split): images/s of the headline bench with the
-# shipped library (no SLP in gemm_mfma.hip / conv_bwd.hip) against `python -m onepose_plus_plus_amd.build --variant slp`
+# shipped library (no SLP in gemm_mfma.hip) against `python -m onepose_plus_plus_amd.build --variant slp`
 for r in 1 2 3; do
   for v in default slp; do
     if [ $v = slp ]; then export OPP_HIP_LIB=$PWD/onepose_plus_plus_amd/libopp_hip_slp.so; else unset OPP_HIP_LIB; fi

@@ -11,6 +11,7 @@ python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_
 python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_driver.json 2> gpurun_out/final_bench_driver.err
 python tools/smi_trace.py --out gpurun_out/final_smi -- python bench.py --steps 200 --warmup 5 --cpu-seconds 0 --no-legs --no-roofline > gpurun_out/final_smi.log 2>&1
 python tools/train_probe.py > gpurun_out/final_train_probe.txt 2> gpurun_out/final_train_probe.err
+python tools/conv_bwd_bench.py 4 > gpurun_out/final_conv_bwd_bench.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 # single stream, fine branch on the same stream, the tiles of the timed region: the condition of bench.py's roofline pass
 OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
