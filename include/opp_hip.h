@@ -125,10 +125,11 @@ size_t opp_packed_weights_bytes(const opp_ctx* ctx);
  * channel padding, concatenates q/k/v projections, transposes the keypoint MLP. */
 int opp_pack_weights(opp_ctx* ctx, const float* const* weights, int n_weights, void* packed,
                      size_t packed_bytes, void* stream);
-/* What the NEXT opp_pack_weights lays out: 0 (default) = everything; 1 = the backbone convolutions only -- for the training step's
- * graph (onepose_plus_plus_amd/train_autograd.py), whose transformer / keypoint-encoder nodes read the parameters directly and repack
- * every step; opp_transformer / opp_coarse_tokens / opp_encode_points / opp_forward_coarse / opp_fine then refuse to run until the
- * weights are packed with scope 0 again. */
+/* What the NEXT opp_pack_weights lays out: 0 (default) = everything; 1 = a training step: only the backbone convolutions WITHOUT a
+ * BatchNorm behind them (the others are packed raw by opp_pack_train_weights; the training graph's transformer / keypoint-encoder
+ * nodes, onepose_plus_plus_amd/train_autograd.py, read the parameters directly) -- the per-step repacking is then ~80 launches
+ * shorter.  opp_backbone / opp_transformer / opp_coarse_tokens / opp_encode_points / opp_forward_coarse / opp_fine refuse to run
+ * until the weights are packed with scope 0 again. */
 int opp_set_pack_scope(opp_ctx* ctx, int scope);
 
 /* ---- training-mode forward of the backbone ------------------------------

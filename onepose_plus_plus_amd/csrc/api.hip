@@ -103,10 +103,12 @@ struct opp_ctx {
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
   bool train_packed = false;
-  // opp_set_pack_scope: 0 = opp_pack_weights lays out everything; 1 = the backbone only (the training graph reads the transformer /
+  // opp_set_pack_scope: 0 = opp_pack_weights lays out everything; 1 = a training step: only the convolutions without BatchNorm (the
+  // others come from opp_pack_train_weights, the training graph reads the transformer /
   // keypoint-encoder parameters directly): `tr_packed` says whether the packed blob holds the transformer + keypoint-MLP weights
   int pack_scope = 0;
   bool tr_packed = false;
+  bool bn_packed = false;   // the BatchNorm-folded (eval) packing of the backbone convolutions is present (scope 0 only)
   // fine-branch overlap of opp_forward_coarse (opp_config.fpn_overlap): a side stream and two events, created on first use
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -404,16 +406,31 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     const int b = d.bn_idx;
     return opp_fold_bn(w[b], w[b + 1], w[b + 2], w[b + 3], eps, d.cout, pad32(d.cout), scale, d.bias, s);
   };
-  // stem (resnet.py:101-103)
-  OPP_TRY(fold(c->stem, c->scratch_scale));
-  OPP_TRY(opp_pack_stem(w[c->stem.w_idx], c->scratch_scale, c->stem.cout, c->stem.w, s));
+  // A packed matrix goes through the staging buffer when the arithmetic pre-splits it: pack -> staging, split -> its place (no copy back)
+  const int prec = gemm_prec(c->cfg);
+  auto place = [&](float* dst, size_t nfl, float* sc, auto&& pack_into) -> int {
+    if (!c->cfg.gemm_precision) return pack_into(dst);
+    OPP_TRY(pack_into(c->scratch_h2));
+    return prec == OPP_PREC_BF16X3 ? opp_b3_split(c->scratch_h2, dst, nfl, s) : opp_h2_split(c->scratch_h2, dst, nfl, sc, s);
+  };
+  // scope 1 (a training step): the BatchNorm-folded packing is not produced -- train() forwards read the raw weights of
+  // opp_pack_train_weights, the convolutions without BatchNorm are shared
+  const bool with_bn = c->pack_scope == 0;
+  if (with_bn) {   // stem (resnet.py:101-103)
+    OPP_TRY(fold(c->stem, c->scratch_scale));
+    OPP_TRY(place(c->stem.w, (size_t)c->stem.cout * 64, c->stem.h2s,
+                  [&](float* dst) { return opp_pack_stem(w[c->stem.w_idx], c->scratch_scale, c->stem.cout, dst, s); }));
+  }
   for (ConvDesc* d : all_convs(c)) {
     const float* scale = nullptr;
     if (d->bn_idx >= 0) {
+      if (!with_bn) continue;
       OPP_TRY(fold(*d, c->scratch_scale));
       scale = c->scratch_scale;
     }
-    OPP_TRY(opp_pack_conv(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), d->w, s));
+    OPP_TRY(place(d->w, d->w_floats(), d->h2s, [&](float* dst) {
+      return opp_pack_conv(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), dst, s);
+    }));
   }
   const bool with_tr = c->pack_scope == 0;
   if (c->cfg.kpt_enc_enable && with_tr) {
@@ -450,15 +467,12 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     OPP_TRY(pack_tr(c->coarse, c->cfg.coarse_d_model));
     OPP_TRY(pack_tr(c->fine, c->cfg.fine_d_model));
   }
-  if (c->cfg.gemm_precision) {   // pre-split every GEMM weight matrix: fp16 hi/lo (same footprint) or bf16 hi/mid/lo (1.5x)
-    const int prec = gemm_prec(c->cfg);
+  if (c->cfg.gemm_precision) {   // pre-split the transformer's GEMM weight matrices: fp16 hi/lo (same footprint) or bf16 hi/mid/lo (1.5x)
     auto split = [&](float* wm, size_t n, float* sc) -> int {
       if (prec == OPP_PREC_BF16X3) OPP_TRY(opp_b3_split(wm, c->scratch_h2, n, s));
       else OPP_TRY(opp_h2_split(wm, c->scratch_h2, n, sc, s));
       return copy_f(wm, c->scratch_h2, split_floats(n, prec), s);
     };
-    OPP_TRY(split(c->stem.w, (size_t)c->stem.cout * 64, c->stem.h2s));
-    for (ConvDesc* d : all_convs(c)) OPP_TRY(split(d->w, d->w_floats(), d->h2s));
     for (auto* L : {&c->coarse, &c->fine}) {
       const size_t d = (L == &c->coarse) ? c->cfg.coarse_d_model : c->cfg.fine_d_model;
       if (!with_tr) break;
@@ -472,12 +486,13 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
   }
   c->packed = true;
   c->tr_packed = with_tr;
+  c->bn_packed = with_bn;
   c->packed_bytes = need;
   return OPP_OK;
 }
 
 extern "C" int opp_set_pack_scope(opp_ctx* ctx, int scope) {
-  OPP_CHECK_ARG(ctx && (scope == 0 || scope == 1), "set_pack_scope: scope must be 0 (everything) or 1 (backbone only)");
+  OPP_CHECK_ARG(ctx && (scope == 0 || scope == 1), "set_pack_scope: scope must be 0 (everything) or 1 (training step: raw backbone weights only)");
   ctx->pack_scope = scope;
   return OPP_OK;
 }
@@ -517,20 +532,20 @@ extern "C" int opp_pack_train_weights(opp_ctx* c, const float* const* w, int n, 
   const size_t need = plan_pack_train(c, packed);
   OPP_CHECK_ARG(bytes >= need, "pack_train: blob too small (%zu < %zu)", bytes, need);
   const int prec = gemm_prec(c->cfg);
-  auto split = [&](float* wm, size_t nfl, float* sc) -> int {
-    if (prec == OPP_PREC_FP32) return OPP_OK;
-    if (prec == OPP_PREC_BF16X3) OPP_TRY(opp_b3_split(wm, c->scratch_h2, nfl, s));
-    else OPP_TRY(opp_h2_split(wm, c->scratch_h2, nfl, sc, s));
-    return copy_f(wm, c->scratch_h2, split_floats(nfl, prec), s);
+  auto place = [&](float* dst, size_t nfl, float* sc, auto&& pack_into) -> int {   // as in opp_pack_weights: pack -> staging, split -> its place
+    if (prec == OPP_PREC_FP32) return pack_into(dst);
+    OPP_TRY(pack_into(c->scratch_h2));
+    return prec == OPP_PREC_BF16X3 ? opp_b3_split(c->scratch_h2, dst, nfl, s) : opp_h2_split(c->scratch_h2, dst, nfl, sc, s);
   };
-  OPP_TRY(opp_pack_stem(w[c->stem.w_idx], nullptr, c->stem.cout, c->stem.w_train, s));
-  OPP_TRY(split(c->stem.w_train, (size_t)c->stem.cout * 64, c->stem.h2s_train));
+  OPP_TRY(place(c->stem.w_train, (size_t)c->stem.cout * 64, c->stem.h2s_train,
+                [&](float* dst) { return opp_pack_stem(w[c->stem.w_idx], nullptr, c->stem.cout, dst, s); }));
   c->stem.gamma = w[c->stem.bn_idx];
   c->stem.beta = w[c->stem.bn_idx + 1];
   for (ConvDesc* d : all_convs(c)) {
     if (d->bn_idx < 0) continue;
-    OPP_TRY(opp_pack_conv(w[d->w_idx], nullptr, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), d->w_train, s));
-    OPP_TRY(split(d->w_train, d->w_floats(), d->h2s_train));
+    OPP_TRY(place(d->w_train, d->w_floats(), d->h2s_train, [&](float* dst) {
+      return opp_pack_conv(w[d->w_idx], nullptr, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), dst, s);
+    }));
     d->gamma = w[d->bn_idx];          // caller-owned: must outlive the training forwards
     d->beta = w[d->bn_idx + 1];
   }
@@ -649,6 +664,7 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
 int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s, int phase = 0,
                   BackboneBufs* bufs = nullptr) {
   OPP_CHECK_ARG(c && c->packed, "backbone: weights not packed");
+  OPP_CHECK_ARG(c->bn_packed, "backbone: weights were packed with scope 1 (training step: no BatchNorm-folded convolutions); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone: H,W must be multiples of 8 (got %dx%d)", H, W);
   BackboneBufs local;
   BackboneBufs& b = bufs ? *bufs : local;
