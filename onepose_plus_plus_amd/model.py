@@ -345,7 +345,7 @@ class OnePosePlus_model(nn.Module):
         return c
 
     def _ensure_ready(self, device, scope=0):
-        """scope 1 (training graph): only the backbone is packed -- the other stages read the parameters themselves"""
+        """scope 1 (training graph): only the raw backbone weights are packed (no BatchNorm folding) -- the other stages read the parameters themselves"""
         lib = _lib.load()
         rt = self._rt
         if rt.get("scope", 0) != scope:
