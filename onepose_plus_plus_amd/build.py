@@ -30,6 +30,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; +0.4 % images/s, profiles/r04_ab_slp_vectorizer.txt).  The scalar and
 # the packed forms contract into FMAs differently, so arithmetic that two files must round identically (the LayerNorm of the fused
 # encoder chain against the launch-per-Linear path) is written with explicit FMAs (opp_common.h: opp_ln_*), not left to the flags.
+# (Every source without the vectorizer, `--variant noslp_all`: +0.2 % at most and the coarse-level chain loses its bit-identity through the
+# attention arithmetic -- profiles/r04_ab_slp_all_sources.txt -- so the other files keep it.)
 SOURCE_FLAGS = {"conv_bwd.hip": ["-fno-slp-vectorize"], "gemm_mfma.hip": ["-fno-slp-vectorize"]}
 
 
@@ -62,7 +64,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True, tuning=False, variant=None):
-    """variant: A/B builds for tools/ (libopp_hip_<variant>.so): "slp" = gemm_mfma.hip with the SLP vectorizer left on"""
+    """variant: A/B builds for tools/ (libopp_hip_<variant>.so): "slp" = gemm_mfma.hip with the SLP vectorizer left on; "noslp_all" = no source with it"""
     suffix = "_tuning" if tuning else ("_" + variant if variant else "")
     obj_dir = OBJ + suffix
     lib_path = LIB.replace(".so", suffix + ".so")
@@ -70,6 +72,8 @@ def build(force=False, verbose=True, tuning=False, variant=None):
     extra = dict(SOURCE_FLAGS)
     if variant == "slp":
         extra.pop("gemm_mfma.hip", None)
+    if variant == "noslp_all":
+        flags = flags + ["-fno-slp-vectorize"]
     return _build(force, verbose, obj_dir, lib_path, flags, extra)
 
 
