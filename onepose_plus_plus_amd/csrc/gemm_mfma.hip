@@ -58,9 +58,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   constexpr int TN = (NT32 + WAVES_N - 1) / WAVES_N;          // per wave (last wave may own fewer)
   constexpr bool kRagged = (NT32 % WAVES_N) != 0;             // e.g. 224 columns on 2 waves = 4 + 3
   constexpr int A_LD = BM * 8 / NT;
-  constexpr int B_LD = H3 ? BN * 12 / NT : BN * 8 / NT;   // bf16x3 weights: 192 B per row and chunk
+  constexpr int B_LD = H3 ? (BN * 12 + NT - 1) / NT : BN * 8 / NT;   // bf16x3 weights: 192 B per row and chunk
+  // a 192-column tile (tuning builds: 196 = 192 + a tail) has 4.5 weight pieces per thread: the upper half of the workgroup loads zeros
+  // for its fifth piece and does not store it
+  constexpr bool kBFrac = H3 && (BN * 12) % NT != 0;
   static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
-  static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 : (BN * 8) % NT == 0), "load split");
+  static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 || BN == 192 : (BN * 8) % NT == 0), "load split");
 
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (ABL == 9 || ABL > 90) ts0 = __builtin_readcyclecounter();
@@ -142,7 +145,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       const int u = tid + i * NT;
       const int row = u / 12, c = u - row * 12;
       const int n = n0 + row;
-      b_base[i] = n < g.N ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
+      if constexpr (kBFrac) b_base[i] = (n < g.N && u < BN * 12) ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
+      else b_base[i] = n < g.N ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
       b_lds[i] = row * kLdsStride + c * 4;
     } else {
       const int n = n0 + lrow + i * (NT / 8);
@@ -324,7 +328,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         *reinterpret_cast<float4*>(row + kq * 4) = a_reg[i];
       }
     } else {
-      *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
+      if constexpr (kBFrac) {
+        if (tid + (i - A_LD) * NT < BN * 12) *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
+      } else {
+        *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
+      }
     }
   };
   auto store_lds = [&](int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
@@ -1036,9 +1044,15 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // split-operand variants are instantiated for the tiles their policies can pick only (depth 2: deeper prefetch measured
   // no better with the shorter MFMA phase; the 4-wave 128-column tiles are fp32 tiles)
   // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
+#ifdef OPP_TUNING
+  constexpr bool kTuning192 = BM == 128 && BN == 192 && NT == 512 && PREC == OPP_PREC_BF16X3;   // tile config 140 of the tuning library
+#else
+  constexpr bool kTuning192 = false;
+#endif
   constexpr bool ok = PREC == OPP_PREC_FP32 ||
                       (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64) || (PREC == OPP_PREC_FP16X2 && BM == 128 && BN == 128)) &&
-                       (BN == 128 || BN == 64 || BN == 256) && (PREC != OPP_PREC_BF16X3 || ((BN * 12) % NT == 0 && BM * BN / NT <= 64)));
+                       (BN == 128 || BN == 64 || BN == 256 || kTuning192) &&
+                       (PREC != OPP_PREC_BF16X3 || (BN * 12) % NT == 0 || kTuning192) && (PREC != OPP_PREC_BF16X3 || BM * BN / NT <= 64 || kTuning192));
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
@@ -1121,6 +1135,9 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
     case 191: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 91>(g, stream) : OPP_ERR_INVALID;   // no global loads
     case 192: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores
     case 193: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
+    // 192-column tile for the 196-channel layers as 192 + a 4-column tail: 32 x 96 per wave, 219 registers, no scratch, 133 KB of LDS
+    // (the 256 x 192 tile, 64 x 96 per wave, spills 248 bytes: not built).  NOT measured yet -- compiled for the next conv_bench runs.
+    case 140: return h3 ? launch_prec<128, 192, 4, 2, 2, OPP_PREC_BF16X3>(g, stream, 0) : OPP_ERR_INVALID;
     case 101: return g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID;
     case 102: return g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID;
     case 103: return g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID;
