@@ -18,7 +18,8 @@ CONVS = [
     ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 20, 25, 27, 106, 107, 101, 105, 102, 103]),
     ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11, 20, 25, 27]),
     ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 11, 10, 0, 20, 22, 25, 27, 28]),
-    # 196 = 192 + a 4-column tail: the 192-column part on the tuning library's 128 x 192 tile (config 140, OPP_HIP_LIB=..._tuning.so)
+    # 196 = 192 + a 4-column tail: the 192-column part on the tuning library's 128 x 192 tile (config 140; run with
+    # OPP_HIP_LIB=.../libopp_hip_tuning.so OPP_ABLATE=1, configs >= 100 are skipped otherwise)
     ("l1_out2a-192 3x3 196->192 @256", 256, 256, 196, 192, 3, 1, [140, 22, 25]),
     ("layer2-192 3x3 196->192 @128", 128, 128, 196, 192, 3, 1, [140, 25, 26]),
     ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 1, 2, 0, 25, 26]),
