@@ -91,13 +91,17 @@ MFMA_SYMBOLS = [
     (1014, "opp_gemm_kernel<128, 128, 4, 2, true> x 4 K slices", "3x3 convolutions of the 1/8-resolution stage (4096 pixels, K = 1792 .. 2304) as "
                                                                   "four K slices on 8-wave tiles: 256 workgroups instead of 64 four-wave ones"),
 ]
-EMPTY_KERNEL_US = 3.6        # average duration of opp_empty_kernel in the rocprofv3 kernel trace (profiles/r04_kernel_stats_bench_streams1.csv)
+EMPTY_KERNEL_US = 3.6        # fallback only: duration of opp_empty_kernel in the rocprofv3 kernel trace of round 4; the run measures its own (roofline_leg)
 HBM_SYMBOLS = [
     (1000, "linattn_kv_mfma_kernel", "linear-attention gather: sum_s phi(K_s)^T V_s (K, V read once + chunk partials written)"),
     (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
     (1002, "conf_reg_kernel", "dual-softmax product over the N x L score matrix (read + written once)"),
     (1015, "splitk_epilogue_kernel", "K slices of a split convolution summed in slice order + bias / residual / activation"),
+    (1016, "linattn_reduce_pair_kernel", "fixed-order sum of the attention gather's chunk partials (partials read, KV / Ksum written)"),
 ]
+# launch shapes that are ONE kernel symbol in a rocprofv3 trace: (symbol of the entry that absorbs, symbol absorbed).  The K slices of the
+# 1/8-resolution convolutions run the same template instance as the 128x128 convolutions of the 1/4-resolution stage.
+SAME_SYMBOL = [("128, 128, 4, 2, true, 0, 2, 2", "opp_gemm_kernel<128, 128, 4, 2, true> x 4 K slices")]
 
 
 def free_port():
@@ -470,9 +474,12 @@ def compact_legs(legs):
         out["fine"] = f
     tr = legs.get("train_leg") or {}
     if "step_ms" in tr:
-        out["train"] = {k: tr.get(k) for k in ("forward_ms", "step_ms", "backward_ms_in_opp_kernels", "backward_kernel_split", "step_samples_per_s")}
+        out["train"] = {k: tr.get(k) for k in ("forward_ms", "step_ms", "backward_ms_in_opp_kernels", "backward_kernel_split", "step_samples_per_s", "roofline")}
     elif tr:
         out["train"] = tr
+    t15 = legs.get("train_leg_n15000") or {}
+    if t15:
+        out["train_n15000"] = {k: t15.get(k) for k in ("forward_ms", "step_ms", "step_samples_per_s", "roofline", "error") if k in t15}
     return out
 
 
@@ -515,9 +522,13 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
         with open(tpath) as f:
             traffic = json.load(f)
     meas = []
-    ov = ctypes.c_double()
+    ov, ek = ctypes.c_double(), ctypes.c_double()
     _lib.check(lib.opp_profile_event_overhead(200, ctypes.byref(ov), torch.cuda.current_stream(dev).cuda_stream), "profile_event_overhead")
     event_pair_us = ov.value          # what an (event, empty kernel, event) triple reads: the floor of every measurement below
+    # the empty kernel's own duration, measured in this run: 400 of them back to back between ONE event pair (the launch-to-launch
+    # interval of a kernel that does nothing = what the rocprofv3 kernel trace shows as its duration, 3.6 us in round 4)
+    _lib.check(lib.opp_profile_empty_kernel(400, ctypes.byref(ek), torch.cuda.current_stream(dev).cuda_stream), "profile_empty_kernel")
+    empty_kernel_us = ek.value if 0.5 < ek.value < 20.0 else EMPTY_KERNEL_US
     for cfg_id, kind, tile, what in GEMM_SYMBOLS:
         spid = 0 if (kind == 2 and precision == "fp16x2") else pid      # fp16x2: the score GEMM stays fp32
         ms, fl, n = prof_run(lib, _lib, torch, dev, step, cfg_id, kind, nsteps)
@@ -558,9 +569,31 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     # trace is EMPTY_KERNEL_US), so event_pair_us - EMPTY_KERNEL_US of every reading is not the kernel: 30 ... 60 % of a sub-15-us
     # launch, 5 ... 15 % of a 40-us one.  `frac` stays the raw reading; `frac_event_corrected` is what the kernel trace shows.
     for m in meas:
-        t = max(m["avg_launch_us"] - max(event_pair_us - EMPTY_KERNEL_US, 0.0), 0.25 * m["avg_launch_us"])
+        t = max(m["avg_launch_us"] - max(event_pair_us - empty_kernel_us, 0.0), 0.25 * m["avg_launch_us"])
         m["avg_launch_us_event_corrected"] = round(t, 2)
         m["frac_event_corrected"] = round(m["frac"] * m["avg_launch_us"] / t, 4)
+    # one entry per KERNEL SYMBOL (what a rocprofv3 trace lists): launch shapes of the same template instance are merged, their own
+    # figures stay under `launch_shapes`, and the dominant kernel is picked by the merged time per forward
+    for keep_sym, gone_sym in SAME_SYMBOL:
+        a = next((m for m in meas if m["symbol"] == keep_sym), None)
+        b = next((m for m in meas if m["symbol"] == gone_sym), None)
+        if a is None or b is None:
+            continue
+        shapes = [{k: x.get(k) for k in ("kernel", "launches_per_forward", "avg_launch_us", "avg_launch_us_event_corrected", "us_per_forward",
+                                        "alg_gflop_per_launch", "achieved", "frac", "frac_event_corrected", "traffic")} for x in (a, b)]
+        n = a["launches"] + b["launches"]
+        us_f = a["us_per_forward"] + b["us_per_forward"]
+        fl = a["alg_gflop_per_launch"] * a["launches"] + b["alg_gflop_per_launch"] * b["launches"]          # GFLOP over the pass
+        tot_us = a["avg_launch_us"] * a["launches"] + b["avg_launch_us"] * b["launches"]
+        tot_us_c = a["avg_launch_us_event_corrected"] * a["launches"] + b["avg_launch_us_event_corrected"] * b["launches"]
+        ach = fl * 1e9 / (tot_us * 1e-6) / 1e12
+        a.update({"launches": n, "launches_per_forward": round(a["launches_per_forward"] + b["launches_per_forward"], 2),
+                  "avg_launch_us": round(tot_us / n, 2), "avg_launch_us_event_corrected": round(tot_us_c / n, 2),
+                  "us_per_forward": round(us_f, 1), "alg_gflop_per_launch": round(fl / n, 3), "achieved": round(ach, 2),
+                  "frac": round(ach / a["peak"], 4), "frac_event_corrected": round(ach / a["peak"] * tot_us / tot_us_c, 4),
+                  "traffic": None, "launch_shapes": shapes,
+                  "kernel": a["kernel"] + " -- all launch shapes of this symbol: unsplit (1/4-resolution stage) + 4 K slices (1/8-resolution stage)"})
+        meas.remove(b)
     meas.sort(key=lambda m: -m["us_per_forward"])
     # the line stays short enough for log tails: strings every entry shares are kept once, on the dominant kernel's entry
     src = None
@@ -575,8 +608,9 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
         roof["traffic_source"] = src
     roof["other_kernels"] = meas[1:]
     roof["event_pair_us"] = round(event_pair_us, 2)
-    roof["event_correction"] = ("frac_event_corrected: launch time minus (event_pair_us - %.1f us) = the reading of an empty kernel between two "
-                                "events minus its duration in the kernel trace" % EMPTY_KERNEL_US)
+    roof["empty_kernel_us"] = round(empty_kernel_us, 2)
+    roof["event_correction"] = ("frac_event_corrected: launch time minus (event_pair_us - empty_kernel_us) = the reading of an empty kernel between "
+                                "two events minus its own back-to-back duration, both measured in this run")
     return roof
 
 
@@ -667,19 +701,25 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
         legs["train_leg"] = train_leg(torch, dev, precision)
     except Exception as e:
         legs["train_leg"] = {"error": str(e)}
+    try:
+        torch.cuda.empty_cache()
+        legs["train_leg_n15000"] = train_leg(torch, dev, precision, N=15000, light=True)
+    except Exception as e:
+        legs["train_leg_n15000"] = {"error": str(e)[:300]}
+    torch.cuda.empty_cache()
     return legs
 
 
-def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
+def train_leg(torch, dev, precision, nsteps=2, step_profiler=None, N=7000, light=False):
     """One training step at the per-GPU shape of BASELINE configs[4] (B = 4, 512x512, N = 7000 points padded as the
     reference's dataset does, train.yaml:185,194): train()-mode forward on the HIP path (BatchNorm batch statistics,
     training branch of get_coarse_match, fine level on the padded matches) built ONCE as a graph of autograd nodes whose
     forward and backward are HIP kernels (onepose_plus_plus_amd/train_autograd.py: backbone with a tape, Linear, linear
     attention, LayerNorm, coarse matcher, fine windows), `fine_supervision` + `Loss` of this package (focal loss over the
     115 M-entry confidence matrix and its gradient in HIP), backward through those nodes and an AdamW update."""
-    from onepose_plus_plus_amd import OnePosePlus_model, default_config
+    from onepose_plus_plus_amd import OnePosePlus_model, default_config, _lib
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
-    B, N, hw = 4, 7000, (512, 512)
+    B, hw = 4, (512, 512)
     cfg = default_config(thr=0.2)
     model = OnePosePlus_model(cfg).set_gemm_precision(precision).to(dev)
     model.load_state_dict(make_state_dict(cfg, 0), strict=True)
@@ -742,6 +782,33 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
 
     fwd_ms, _ = timed(fwd_only)
     step_ms, loss = timed(full_step)
+    # roofline of the step: a training step is ~3x the forward's FLOPs (forward + input gradients + weight gradients), MFMA-bound;
+    # its largest kernel is conv_wgrad_kernel (every convolution's and every Linear's weight gradient), timed with HIP events on the
+    # launch stream over one more step
+    lib = _lib.load()
+    flops_fwd = B * 2.0 * (126.726e9 + 6 * (4096 + N) * 671744 + N * 4096 * 256)
+    peak = MFMA_PEAK[precision]
+    roof = {"bound": "mfma", "step_alg_tflop": round(3 * flops_fwd / 1e12, 3), "achieved": round(3 * flops_fwd / (step_ms * 1e-3) / 1e12, 2),
+            "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(3 * flops_fwd / (step_ms * 1e-3) / 1e12 / peak, 4),
+            "note": "step FLOPs = 3 x the forward's algorithmic FLOPs over the batch (coarse level; the fine level adds < 2 %)"}
+    try:
+        _lib.check(lib.opp_profile_start(1013, 0, 4096), "profile_start")
+        full_step()
+        torch.cuda.synchronize(dev)
+        ms, wk, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(lib.opp_profile_stop(ctypes.byref(ms), ctypes.byref(wk), ctypes.byref(nl)), "profile_stop")
+        if nl.value > 0 and ms.value > 0:
+            ach = wk.value / (ms.value * 1e-3) / 1e12
+            roof["dominant_kernel"] = {"kernel": "conv_wgrad_kernel (weight gradient of every convolution and Linear, pixel-major operands)",
+                                       "launches_per_step": nl.value, "ms_per_step": round(ms.value, 3), "alg_gflop_per_step": round(wk.value / 1e9, 1),
+                                       "achieved": round(ach, 2), "frac": round(ach / peak, 4),
+                                       "measured": "HIP events on the launch stream around every launch of one step"}
+    except Exception as e:
+        roof["dominant_kernel"] = {"error": str(e)[:120]}
+    if light:
+        return {"workload": "as train_leg with N = %d points per sample (BASELINE configs[4]: '15k-point clouds')" % N,
+                "forward_ms": round(fwd_ms, 2), "step_ms": round(step_ms, 1), "step_samples_per_s": round(B / step_ms * 1e3, 2),
+                "loss": round(loss, 5), "roofline": roof}
     if step_profiler is not None:            # tools/train_probe.py: a profiler context around warmed-up steps only
         with step_profiler:
             for _ in range(nsteps):
@@ -751,8 +818,9 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
     focal_ms = min(loss_only() for _ in range(3))
     bwd = backward_kernel_split(torch, dev, model, base, hparams, loss_mod, fine_supervision)
     n_conf = B * N * 4096
-    return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, 7000 points, train() mode, single stream; "
-                        "step = model(batch), fine_supervision, Loss (focal + l2_with_std, train.yaml:129-144), backward, AdamW",
+    return {"workload": "BASELINE configs[4] per-GPU shape: B = 4, 512x512, %d points, train() mode, single stream; "
+                        "step = model(batch), fine_supervision, Loss (focal + l2_with_std, train.yaml:129-144), backward, AdamW" % N,
+            "roofline": roof,
             "forward_ms": round(fwd_ms, 2), "forward_samples_per_s": round(B / fwd_ms * 1e3, 1),
             "step_ms": round(step_ms, 1), "step_samples_per_s": round(B / step_ms * 1e3, 2), "loss": round(loss, 5),
             "focal_loss_fwd_bwd_ms": round(focal_ms, 3),
@@ -762,10 +830,37 @@ def train_leg(torch, dev, precision, nsteps=2, step_profiler=None):
                     "attention, LayerNorm, dual softmax, focal loss); PyTorch = autograd tape, elementwise glue, AdamW"}
 
 
+def library_kernel_names():
+    """names of every __global__ kernel of libopp_hip.so, read from the sources next to it (csrc/*.hip travel with the library)"""
+    import glob
+    import re
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "onepose_plus_plus_amd", "csrc", "*.hip")):
+        with open(f) as fh:
+            src = fh.read()
+        names.update(re.findall(r"__global__(?:\s+__launch_bounds__\([^)]*\))?\s+void\s+(\w+)\s*\(", src))
+    return names
+
+
+def classify_kernel(name, ours):
+    """-> "ours" (a kernel of libopp_hip.so, matched POSITIVELY by name), "vendor" (MIOpen / rocBLAS / Tensile / rocPRIM / hipCUB /
+    Thrust: somebody else's tuned library), "aten" (PyTorch's own elementwise / reduction / copy kernels) or "other" """
+    import re
+    low = name.lower()
+    if "at::" not in name and "rocprim" not in low and any(tok in ours for tok in re.findall(r"[A-Za-z_]\w*", name)):
+        return "ours"
+    if any(t in low for t in ("miopen", "igemm", "cijk_", "rocblas", "tensile", "rocprim", "hipcub", "thrust", "cub::")):
+        return "vendor"
+    if "at::native" in name or "at::cuda" in name or "memcpy" in low or "memset" in low or "fill" in low or "copybuffer" in low:
+        return "aten"
+    return "other"
+
+
 def backward_kernel_split(torch, dev, model, base, hparams, loss_mod, fine_supervision):
     """Device time of ONE backward pass (loss.backward() of the training step) by who wrote the kernel, from torch.profiler's
-    kernel records: hand-written HIP of libopp_hip.so vs PyTorch's own elementwise / reduction kernels (at::native) vs vendor
-    libraries (MIOpen / rocBLAS / Tensile -- expected: none)."""
+    kernel records: hand-written HIP of libopp_hip.so (matched positively against the kernel names in csrc/*.hip) vs PyTorch's own
+    elementwise / reduction kernels (at::native) vs vendor libraries (MIOpen / rocBLAS / Tensile / rocPRIM behind torch indexing)
+    vs anything else."""
     try:
         from torch.profiler import ProfilerActivity, profile
         d = dict(base)
@@ -778,26 +873,24 @@ def backward_kernel_split(torch, dev, model, base, hparams, loss_mod, fine_super
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             d["loss"].backward()
             torch.cuda.synchronize(dev)
-        ours = aten = vendor = 0.0
-        vendor_names = []
+        lib_names = library_kernel_names()
+        tsum = {"ours": 0.0, "aten": 0.0, "vendor": 0.0, "other": 0.0}
+        seen = {"vendor": [], "other": []}
         for e in prof.key_averages():
             t = getattr(e, "self_device_time_total", None)
             if t is None:
                 t = getattr(e, "self_cuda_time_total", 0.0)
             if not t:
                 continue
-            name = e.key
-            low = name.lower()
-            if "miopen" in low or "igemm" in low or "cijk_" in low or "rocblas" in low or "tensile" in low:
-                vendor += t
-                vendor_names.append(name[:60])
-            elif "at::native" in name or "at::cuda" in name or "memcpy" in low or "memset" in low or "fill" in low:
-                aten += t
-            else:
-                ours += t
-        tot = ours + aten + vendor
-        return {"hand_written_ms": round(ours / 1e3, 2), "aten_elementwise_ms": round(aten / 1e3, 2), "vendor_library_ms": round(vendor / 1e3, 2),
-                "hand_written_frac": round(ours / tot, 3) if tot else None, "vendor_kernels": vendor_names[:6]}
+            kind = classify_kernel(e.key, lib_names)
+            tsum[kind] += t
+            if kind in seen:
+                seen[kind].append(e.key[:60])
+        tot = sum(tsum.values())
+        return {"hand_written_ms": round(tsum["ours"] / 1e3, 2), "aten_elementwise_ms": round(tsum["aten"] / 1e3, 2),
+                "vendor_library_ms": round(tsum["vendor"] / 1e3, 2), "other_ms": round(tsum["other"] / 1e3, 2),
+                "hand_written_frac": round(tsum["ours"] / tot, 3) if tot else None, "vendor_kernels": seen["vendor"][:6],
+                "other_kernels": seen["other"][:6]}
     except Exception as e:                    # the split is a report, never a reason to lose the leg
         return {"error": str(e)[:200]}
 
@@ -877,18 +970,19 @@ def cpu_baseline(torch, cfg, sd, args, make_inputs):
     from oracle import onepose_oracle as O
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     data = make_inputs(args.n_points, (args.hw, args.hw), seed=1)
-    small = make_inputs(500, (128, 128), seed=1)
-    best = None
-    for th in sorted({min(avail, c) for c in (8, 16, 32, 64)}):
+    # thread count calibrated on the FULL-SIZE workload (round-4 review: a 128x128 x 500-point toy picked 16 threads, the real
+    # forward may prefer more): one warm-up + one timed forward per candidate, ~1 s each
+    best, calib = None, {}
+    for th in sorted({min(avail, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(th)
-        O.forward(sd, dict(small), cfg)
+        O.forward(sd, dict(data), cfg)
         t = time.perf_counter()
-        O.forward(sd, dict(small), cfg)
+        O.forward(sd, dict(data), cfg)
         dt = time.perf_counter() - t
+        calib[th] = round(dt, 3)
         if best is None or dt < best[1]:
             best = (th, dt)
     torch.set_num_threads(best[0])
-    O.forward(sd, dict(data), cfg)            # warm-up at full size
     times = []
     t_end = time.perf_counter() + args.cpu_seconds
     while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 50):
@@ -905,8 +999,9 @@ def cpu_baseline(torch, cfg, sd, args, make_inputs):
     one = time.perf_counter() - t
     torch.set_num_threads(used)
     return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": used, "kind": "port", "one_thread_images_per_s": round(1.0 / one, 4),
+            "thread_calibration_s_per_forward": calib,
             "sample": "%d forwards of the same %dx%d x %d-pt workload through oracle/onepose_oracle.py "
-                      "(fp32 PyTorch CPU, %d of %d available threads), median; min %.3f s"
+                      "(fp32 PyTorch CPU, %d of %d available threads: the fastest of {8, 16, 32, 64, 128} on this full-size workload), median; min %.3f s"
                       % (len(times), args.hw, args.hw, args.n_points, best[0], avail, min(times))}
 
 

@@ -431,6 +431,8 @@ int opp_profile_start(int tile_cfg, int kind, int capacity_launches);
  * after, all pairs enqueued back to back, one synchronisation at the end); *mean_us = mean elapsed time of `launches` pairs.
  * bench.py reports it beside the sub-15-us symbols and corrects their roofline fractions by it. */
 int opp_profile_event_overhead(int launches, double* mean_us, void* stream);
+/* The empty kernel's own duration: `launches` of them back to back between ONE event pair; *mean_us = elapsed / launches. */
+int opp_profile_empty_kernel(int launches, double* mean_us, void* stream);
 int opp_profile_stop(double* total_ms, double* total_work, int* launches);
 
 #ifdef __cplusplus

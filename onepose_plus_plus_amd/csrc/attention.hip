@@ -592,7 +592,10 @@ int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv,
     OppProfScope prof(OPP_PROF_LINATTN_KV, stream, (double)(len0 + len1) * 512.0 * 4.0 + (double)(c0 + c1) * (8192 + 256) * 4.0);
     hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(64), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
   }
-  hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 64), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
+  {  // algorithmic bytes: every chunk partial read once, KV / Ksum of both streams written
+    OppProfScope prof(OPP_PROF_LINATTN_REDUCE, stream, (double)(c0 + c1 + 2) * (8192 + 256) * 4.0);
+    hipLaunchKernelGGL(linattn_reduce_pair_kernel, dim3(opp_cdiv(8192 + 256, 64), 2), dim3(256), 0, stream, kvp, ksp, c0, c1, kv, ks);
+  }
   OPP_CHECK_LAUNCH("linattn_kv_pair");
   return OPP_OK;
 }

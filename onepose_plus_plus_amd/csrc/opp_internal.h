@@ -21,6 +21,7 @@ enum {
   OPP_PROF_SCORE_SWEEP2 = 1011,
   OPP_PROF_CONV_WGRAD = 1013,      // conv_wgrad_kernel: weight gradient of a convolution / Linear (work = FLOPs)
   OPP_PROF_CONV_SPLITK = 1014,     // opp_gemm_kernel<128,128,conv> over 4 K slices: the 3x3 convolutions of the 1/8-resolution stage (FLOPs)
+  OPP_PROF_LINATTN_REDUCE = 1016,  // linattn_reduce_pair_kernel: fixed-order sum of the KV chunk partials (work = bytes)
   OPP_PROF_SPLITK_EPILOGUE = 1015, // splitk_epilogue_kernel: slices summed + bias / residual / activation (work = bytes)
   OPP_PROF_SCORE_SS = 1012,        // gemm_ss_kernel<STATS_STORE>: score GEMM on pre-split operands, statistics + score matrix written (FLOPs)    // gemm_ss_kernel<CONF>: score tiles recomputed -> confidence matrix written once (work = FLOPs)
 };

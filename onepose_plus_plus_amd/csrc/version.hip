@@ -51,3 +51,32 @@ extern "C" int opp_profile_event_overhead(int launches, double* mean_us, void* s
   delete[] ev;
   return rc;
 }
+
+// The empty kernel's own duration: `launches` of them back to back between ONE event pair -> the launch-to-launch interval of a kernel
+// that does nothing, which is what a rocprofv3 kernel trace reports as its duration.  bench.py subtracts it from the event-pair reading above.
+extern "C" int opp_profile_empty_kernel(int launches, double* mean_us, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OPP_CHECK_ARG(launches > 0 && launches <= 65536 && mean_us, "profile_empty_kernel: bad argument");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    opp_set_error("profile_empty_kernel: hipEventCreate failed");
+    return OPP_ERR_LAUNCH;
+  }
+  for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(opp_empty_kernel, dim3(1), dim3(64), 0, stream);
+  (void)hipEventRecord(e0, stream);
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(opp_empty_kernel, dim3(1), dim3(64), 0, stream);
+  (void)hipEventRecord(e1, stream);
+  int rc = OPP_OK;
+  if (hipEventSynchronize(e1) != hipSuccess) {
+    opp_set_error("profile_empty_kernel: hipEventSynchronize failed");
+    rc = OPP_ERR_LAUNCH;
+  } else {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *mean_us = (double)ms * 1e3 / launches;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}

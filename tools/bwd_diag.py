@@ -8,6 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from onepose_plus_plus_amd import train_autograd as TA  # noqa: E402
+from tests import torch_graph_ref as GR  # noqa: E402
 from onepose_plus_plus_amd.config import default_config  # noqa: E402
 from onepose_plus_plus_amd.synthetic import make_state_dict  # noqa: E402
 from tests import hip_ops as ops  # noqa: E402
@@ -21,7 +22,7 @@ def main():
     img = torch.rand(B, 1, H, W, generator=g)
     p = {k: v.double().requires_grad_(k.startswith("backbone.") and not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
          for k, v in sd.items() if v.is_floating_point()}
-    rc, rf = TA._backbone(p, img.double())
+    rc, rf = GR._backbone(p, img.double())
     rc_t, rf_t = rc.flatten(2).transpose(1, 2), rf.flatten(2).transpose(1, 2)
     gfc, gff = torch.randn(rc_t.shape, generator=g), torch.randn(rf_t.shape, generator=g)
     for which in ("both", "coarse_only", "fine_only"):
