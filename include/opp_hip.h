@@ -171,6 +171,21 @@ int opp_coarse_tokens(opp_ctx* ctx, const float* feat_c, const float* pe, int L,
 int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* bank_c, int n_points,
                       float* tokens3d, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Image-independent prefix of the coarse transformer of a RESIDENT object (round 5).  With layer_names = ["self", "cross", ...]
+ * (loftr_module/transformer.py:147-160) layer 0 updates the 3D-point stream from itself only, and in layer 1 both streams read the
+ * PRE-update tokens of the other one, so the 3D stream after layer 0, its layer-1 q / k / v projections and its layer-1 KV / Ksum
+ * depend on (keypoints3d, coarse bank) alone -- OnePosePlusModel.py:160-164 recomputes them per image.  opp_object_prefix evaluates
+ * them once from the tokens of opp_encode_points into a caller-owned blob of opp_object_prefix_bytes() bytes (16-byte aligned;
+ * 0 = this configuration -- another arithmetic, encoder_fusion != 2, other layer names -- has no prefix and every layer is evaluated
+ * per image); opp_set_object_prefix hands the blob to the NEXT opp_forward_coarse calls of this ctx (used when tokens3d_pre is
+ * given and n_points matches; NULL = off).  Results are bit-identical with and without it (rows are independent in every kernel
+ * of a layer, the KV reduction is chunked per stream). */
+size_t opp_object_prefix_bytes(const opp_ctx* ctx, int n_points);
+size_t opp_object_prefix_workspace_bytes(const opp_ctx* ctx, int n_points);
+int opp_object_prefix(opp_ctx* ctx, const float* tokens3d, int n_points, void* prefix, size_t prefix_bytes, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int opp_set_object_prefix(opp_ctx* ctx, const void* prefix, int n_points);
+
 /* LocalFeatureTransformer.forward (loftr_module/transformer.py:133-171), in place on
  * tokens = [n_seg*len0 rows of stream "2D" ; n_seg*len1 rows of stream "3D"] x d_model.
  * which = 0: loftr_coarse, 1: loftr_fine. */

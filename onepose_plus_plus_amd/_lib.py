@@ -78,6 +78,10 @@ SIGNATURES = {
                                  c_void_p, c_size_t, c_void_p]),
     "opp_forward_coarse_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "opp_encode_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_object_prefix_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_object_prefix_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_object_prefix": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "opp_set_object_prefix": (c_int, [c_void_p, c_void_p, c_int]),
     "opp_forward_coarse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

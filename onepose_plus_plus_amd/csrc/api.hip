@@ -100,6 +100,8 @@ struct opp_ctx {
   const float* query_mask = nullptr;      // opp_set_query_mask: [L] floats (0 / 1) of the CURRENT sample, or null
   const float* kpt_extent_ref = nullptr;  // opp_set_keypoint_extent_ref: keypoints of batch element 0 (quirk q4)
   int kpt_extent_n = 0;
+  const float* obj_prefix = nullptr;      // opp_set_object_prefix: result of opp_object_prefix for the CURRENT object, or null
+  int obj_prefix_n = 0;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
   bool train_packed = false;
@@ -1390,12 +1392,43 @@ int dense_gemm(const float* A0, int lda0, const float* A1, int lda1, int ksplit,
   return opp_gemm_launch(g, s);
 }
 
+// Image-independent prefix of the coarse transformer (layer_names = ["self", "cross", ...], transformer.py:147-160): layer 0 updates
+// the 3D-point stream from itself only, and in layer 1 both streams read the PRE-update tokens of the other one (quirk q6), so the
+// 3D stream's layer-1 projections phi(Q) | phi(K) | V / S and its KV / Ksum are functions of the object alone.  Layout of the blob:
+//   x1 [n][C]   3D tokens after layer 0        qkv1 [n][3 C]   their layer-1 projection rows        kv1 [C * D]   ks1 [C]
+struct ObjPrefix {
+  float *x1 = nullptr, *qkv1 = nullptr, *kv1 = nullptr, *ks1 = nullptr;
+};
+size_t obj_prefix_floats(int C, int D, int n) { return (size_t)n * C + (size_t)n * 3 * C + (size_t)C * D + C; }
+ObjPrefix obj_prefix_view(float* base, int C, int D, int n) {
+  ObjPrefix p;
+  p.x1 = base;
+  p.qkv1 = p.x1 + (size_t)n * C;
+  p.kv1 = p.qkv1 + (size_t)n * 3 * C;
+  p.ks1 = p.kv1 + (size_t)C * D;
+  return p;
+}
+// the fused default path only (bf16x3, one 64-token layer kernel per layer): every other configuration computes the whole layer
+bool obj_prefix_ok(const opp_ctx* c) {
+  return c->cfg.gemm_precision == 3 && c->cfg.encoder_fusion == 2 && c->cfg.coarse_n_layers >= 2 && c->cfg.coarse_is_cross[0] == 0 &&
+         c->cfg.coarse_is_cross[1] == 1 && c->cfg.coarse_d_model == 256 && c->cfg.coarse_nhead == 8 && c->tr_packed;
+}
+enum { OPP_PREFIX_NONE = 0, OPP_PREFIX_USE = 1, OPP_PREFIX_MAKE = 2 };
+
 // LocalFeatureTransformer.forward (transformer.py:133-171) on X = [stream0 ; stream1]
+// prefix_mode OPP_PREFIX_USE: X's stream-1 rows already hold ObjPrefix::x1; layer 0 then runs on stream 0 only and layer 1 projects /
+// reduces stream 0 only (the 3D stream's share comes from `pre`).  OPP_PREFIX_MAKE (len0 = 0): layer 0 on the 3D stream, then the
+// layer-1 projection and KV / Ksum of that stream into `pre`, and stop.  Rows are independent in every kernel of a layer and the
+// chunking of the KV reduction is per stream, so both modes reproduce the bits of the full evaluation.
 int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cross, int C, int nhead, float* X, int n_seg,
-                     int len0, int len1, Arena& a, hipStream_t s, int h2, const float* mask0 = nullptr, int fusion = 1) {
+                     int len0, int len1, Arena& a, hipStream_t s, int h2, const float* mask0 = nullptr, int fusion = 1,
+                     int prefix_mode = OPP_PREFIX_NONE, const ObjPrefix* pre = nullptr) {
   const int D = C / nhead;
   const int T0 = n_seg * len0, T1 = n_seg * len1, T = T0 + T1;
   if (T == 0 || layers.empty()) return OPP_OK;
+  if (prefix_mode != OPP_PREFIX_NONE)
+    OPP_CHECK_ARG(pre && n_seg == 1 && C == 256 && D == 32 && fusion == 2 && h2 == OPP_PREC_BF16X3 && layers.size() >= 2 && !is_cross[0] && is_cross[1] &&
+                      (prefix_mode == OPP_PREFIX_USE || len0 == 0), "transformer: object prefix on an unsupported configuration");
   TrBufs b;
   plan_transformer(C, D, n_seg, len0, len1, a, b);
   if (!a.ok) {
@@ -1408,6 +1441,10 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
   for (size_t li = 0; li < layers.size(); ++li) {
     const EncLayerDesc& e = layers[li];
     const bool cross = is_cross[li] != 0;
+    // stream-1 rows this layer projects / reduces (l1_qkv) and updates (l1_lay)
+    const int l1_qkv = (prefix_mode == OPP_PREFIX_USE && li < 2) ? 0 : len1;
+    const int l1_lay = (prefix_mode == OPP_PREFIX_USE && li == 0) ? 0 : len1;
+    const bool make_tail = prefix_mode == OPP_PREFIX_MAKE && li == 1;     // projection + KV of the 3D stream into the prefix, then stop
     {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
       OppGemm g;
       g.nonfinite = t_status_flag;
@@ -1417,10 +1454,10 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.ksplit = C;
       g.W = e.wqkv;
       g.ldw = (int)split_floats((size_t)C, h2);
-      g.M = T;
+      g.M = T0 + n_seg * l1_qkv;
       g.N = 3 * C;
       g.K = C;
-      g.C = b.qkv;
+      g.C = make_tail ? pre->qkv1 : b.qkv;
       g.ldc = 3 * C;
       g.n_store = 3 * C;
       g.act = OPP_ACT_QKV;
@@ -1434,10 +1471,15 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       g.h2_inv = (h2 == OPP_PREC_FP16X2 && e.sqkv) ? e.sqkv + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
     }
+    if (make_tail) {
+      OPP_TRY(opp_linattn_kv_pair(pre->qkv1, 3 * C, 0, len1, b.kv, b.ks, b.scratch, s));
+      OPP_TRY(copy_f(pre->kv1, b.kv + (size_t)C * D, (size_t)C * D, s));
+      return copy_f(pre->ks1, b.ks + C, C, s);
+    }
     // everything behind the projection in ONE launch (bf16x3): [apply ->] merge -> norm1 -> mlp.0 -> ReLU -> mlp.2 -> norm2 -> +x
     const bool chain_apply = n_seg == 1 && C == 256 && D == 32;     // coarse level: the kernel applies KV itself
     if (fusion && h2 == OPP_PREC_BF16X3 && e.fmerge && opp_enc_chain_ok(C, nhead, chain_apply)) {
-      OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, len1, cross, b.kv, b.ks, b.scratch, chain_apply ? nullptr : b.msg, eps_attn, s));
+      OPP_TRY(run_linattn(b.qkv, C, D, n_seg, len0, l1_qkv, cross, b.kv, b.ks, b.scratch, chain_apply ? nullptr : b.msg, eps_attn, s));
       OppEncChain ch;
       ch.C = C;
       ch.X = X;
@@ -1445,7 +1487,12 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
       ch.out = X;
       ch.ldo = C;
       ch.len0 = chain_apply ? len0 : T;
-      ch.len1 = chain_apply ? len1 : 0;
+      ch.len1 = chain_apply ? l1_lay : 0;
+      if (prefix_mode == OPP_PREFIX_USE && li == 1) {   // the 3D stream's share of this layer comes from the object prefix
+        ch.q1 = pre->qkv1;
+        ch.kv1 = pre->kv1;
+        ch.ks1 = pre->ks1;
+      }
       ch.msg = b.msg;
       ch.ldm = C;
       ch.apply = chain_apply ? 1 : 0;
@@ -1510,6 +1557,41 @@ extern "C" int opp_encode_points(opp_ctx* ctx, const float* kpts, const float* b
   OPP_CHECK_ARG(ctx->tr_packed, "encode_points: weights were packed with scope 1 (backbone only); repack with opp_set_pack_scope(ctx, 0)");
   Arena a(ws, ws_bytes);
   return encode_points_impl(ctx, kpts, bank_c, n, tokens3d, a, (hipStream_t)stream);
+}
+
+// ---- per-object prefix of the coarse transformer (see ObjPrefix above) ---------------------------------------------------
+extern "C" int opp_set_object_prefix(opp_ctx* ctx, const void* prefix, int n_points) {
+  OPP_CHECK_ARG(ctx && (prefix == nullptr || n_points > 0), "set_object_prefix: bad argument");
+  ctx->obj_prefix = static_cast<const float*>(prefix);
+  ctx->obj_prefix_n = prefix ? n_points : 0;
+  return OPP_OK;
+}
+
+extern "C" size_t opp_object_prefix_bytes(const opp_ctx* ctx, int n_points) {
+  if (!ctx || n_points <= 0 || !obj_prefix_ok(ctx)) return 0;     // 0: this configuration evaluates the whole layers per image
+  const int C = ctx->cfg.coarse_d_model;
+  return opp_align(obj_prefix_floats(C, C / ctx->cfg.coarse_nhead, n_points) * sizeof(float));
+}
+
+extern "C" size_t opp_object_prefix_workspace_bytes(const opp_ctx* ctx, int n_points) {
+  if (!ctx || n_points <= 0) return 0;
+  return opp_transformer_workspace_bytes(ctx, 0, 1, 0, n_points);
+}
+
+extern "C" int opp_object_prefix(opp_ctx* ctx, const float* tokens3d, int n_points, void* prefix, size_t prefix_bytes, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  FlagScope flag_scope(ctx);
+  OPP_CHECK_ARG(ctx && ctx->packed && tokens3d && prefix && ws && n_points > 0, "object_prefix: bad argument");
+  OPP_CHECK_ARG(obj_prefix_ok(ctx), "object_prefix: this configuration has no image-independent transformer prefix (opp_object_prefix_bytes == 0)");
+  const int C = ctx->cfg.coarse_d_model, D = C / ctx->cfg.coarse_nhead;
+  OPP_CHECK_ARG(prefix_bytes >= obj_prefix_floats(C, D, n_points) * sizeof(float) && (reinterpret_cast<uintptr_t>(prefix) & 15) == 0,
+                "object_prefix: prefix buffer too small or not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  ObjPrefix pre = obj_prefix_view(static_cast<float*>(prefix), C, D, n_points);
+  OPP_TRY(copy_f(pre.x1, tokens3d, (size_t)n_points * C, s));
+  Arena a(ws, ws_bytes);
+  return transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, pre.x1, 1, 0, n_points, a, s, gemm_prec(ctx->cfg), nullptr,
+                          ctx->cfg.encoder_fusion, OPP_PREFIX_MAKE, &pre);
 }
 
 namespace {
@@ -1772,10 +1854,14 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
     }
   } join{ctx, s, forked};
   a.off = mark;
-  OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, tokens3d_pre, tokens, a, s));
+  // resident object with a transformer prefix (opp_set_object_prefix): its 3D tokens enter already past layer 0
+  const bool use_prefix = ctx->obj_prefix != nullptr && ctx->obj_prefix_n == n && tokens3d_pre != nullptr && obj_prefix_ok(ctx);
+  ObjPrefix pre;
+  if (use_prefix) pre = obj_prefix_view(const_cast<float*>(ctx->obj_prefix), C, C / ctx->cfg.coarse_nhead, n);
+  OPP_TRY(coarse_tokens_impl(ctx, feat_c, ctx->cfg.pos_enc_enable ? pe : nullptr, L, kpts, bank_c, n, use_prefix ? pre.x1 : tokens3d_pre, tokens, a, s));
   a.off = mark;
   OPP_TRY(transformer_impl(ctx->coarse, ctx->cfg.coarse_is_cross, C, ctx->cfg.coarse_nhead, tokens, 1, L, n, a, s, gemm_prec(ctx->cfg), ctx->query_mask,
-                           ctx->cfg.encoder_fusion));
+                           ctx->cfg.encoder_fusion, use_prefix ? OPP_PREFIX_USE : OPP_PREFIX_NONE, use_prefix ? &pre : nullptr));
   a.off = mark;
   return coarse_match_impl(ctx, tokens + (size_t)L * C, tokens, n, hc, wc, kpts, base_scale, qscale, conf, i_ids, j_ids, mconf, mkpts_c,
                            mkpts_3d, count, a, s);

@@ -46,6 +46,8 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
   const int seg_len = stream ? a.len1 : a.len0;
   const int row0 = (stream ? a.len0 : 0) + cidx * R64;
   const int nrows = min(R64, seg_len - cidx * R64);
+  // phi(Q) rows of this tile: stream 1 may come from its own buffer (the per-object prefix keeps the image-independent projection)
+  const float* qrows = (stream && a.q1 != nullptr) ? a.q1 + (size_t)(cidx * R64) * a.ldq : a.q + (size_t)row0 * a.ldq;
 
   // ---- GEMM over the operand tile: acc[i][j] += A[rows 32 i ..][k16-steps of the tile] * W[tile t0 + j][steps S0 .. S1)^T ----
   // weights fragment-major (opp_pack_frag_b3): ((t * KS + s) * 3 + part) * 1024 + lane * 16 bytes, KS = steps of the matrix;
@@ -209,8 +211,8 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
   // B operand of the apply: KV_h[d = 2 i + half][v = l31] of this wave's head, in flight during the first GEMM
   const int src = a.cross ? 1 - stream : stream;          // quirk q6: both streams use pre-update K, V
   const float src_len = (float)(src ? a.len1 : a.len0);
-  const float* kvp = a.kv + (size_t)src * (C * D);
-  const float* ksp = a.ks + (size_t)src * C;
+  const float* kvp = (src && a.kv1 != nullptr) ? a.kv1 : a.kv + (size_t)src * (C * D);
+  const float* ksp = (src && a.ks1 != nullptr) ? a.ks1 : a.ks + (size_t)src * C;
   const int h = wave;
   float bk[16];
 #pragma unroll
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
       const int e = tid + i * NT;
       const int r = e / (C / 4), c4 = e - r * (C / 4);
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rh * 32 + r < nrows) q = *reinterpret_cast<const float4*>(a.q + (size_t)(row0 + rh * 32 + r) * a.ldq + c4 * 4);
+      if (rh * 32 + r < nrows) q = *reinterpret_cast<const float4*>(qrows + (size_t)(rh * 32 + r) * a.ldq + c4 * 4);
       float2* dst = reinterpret_cast<float2*>(qsh + r * QS + c4 * 4);
       dst[0] = make_float2(q.x, q.y);
       dst[1] = make_float2(q.z, q.w);
@@ -329,7 +331,7 @@ int opp_enc_layer64(const OppEncChain& a, hipStream_t stream) {
   OPP_CHECK_ARG(a.len0 >= 0 && a.len1 >= 0 && a.len0 + a.len1 > 0, "enc_layer64: empty token set");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   OPP_CHECK_ARG(al16(a.X) && al16(a.out) && al16(a.q) && a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && al16(a.g1) && al16(a.b1) &&
-                    al16(a.g2) && al16(a.b2) && al16(a.wm) && al16(a.w1) && al16(a.w2), "enc_layer64: operands must be 16-byte aligned");
+                    al16(a.g2) && al16(a.b2) && al16(a.wm) && al16(a.w1) && al16(a.w2) && al16(a.q1), "enc_layer64: operands must be 16-byte aligned");
   static OppLdsOnce lds_once;            // per device (opp_common.h)
   opp_lds_opt_in(reinterpret_cast<const void*>(enc_layer64_kernel), kLds64, lds_once);
   const int tiles = opp_cdiv(a.len0, R64) + opp_cdiv(a.len1, R64);

@@ -87,6 +87,11 @@ struct OppEncChain {
   int ldq = 0;
   const float* kv = nullptr;     // [2][C * 32]
   const float* ks = nullptr;     // [2][C]
+  // enc_layer64 only, optional (per-object prefix of the coarse transformer, opp_object_prefix): phi(Q) rows of STREAM 1 from their own
+  // buffer ([len1][ldq]) and the reduced KV / Ksum of stream 1 ([C * 32], [C]) instead of q + len0 rows / kv[1] / ks[1]
+  const float* q1 = nullptr;
+  const float* kv1 = nullptr;
+  const float* ks1 = nullptr;
   int cross = 0;
   float eps_attn = 1e-6f;
   // fragment-major bf16x3 weights (opp_pack_frag_b3): merge [C][C], mlp.0 [2C][2C], mlp.2 [C][2C]

@@ -409,7 +409,7 @@ class OnePosePlus_model(nn.Module):
         return self._rt["pe"][key]
 
     def _object_tokens(self, lib, ctx, kpts, bank_c, device, stream):
-        """Encoded 3D-point tokens [N, C] of the current object.  They depend only on
+        """-> (encoded 3D-point tokens [N, C] of the current object, transformer prefix blob or None).  They depend only on
         (keypoints3d, coarse bank) -- OnePosePlusModel.py:144-156 recomputes them per image -- so
         they are cached per object: the key is the identity AND version counter of both tensors
         (an in-place edit or a different object re-encodes; writes that bypass the version counter
@@ -417,23 +417,31 @@ class OnePosePlus_model(nn.Module):
         them, so reuse from another stream is ordered behind the encoding.  Set
         `cache_object_tokens = False` to encode per image like the reference."""
         if not getattr(self, "cache_object_tokens", True):
-            return None
+            return None, None
         src = (kpts, bank_c)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in src)
         hit = self._rt.get("obj")
         if hit is not None and hit[0] == key and hit[1].device == device:
             if hit[3] is not None:      # encoded on another stream: order this stream behind that work
                 torch.cuda.current_stream(device).wait_event(hit[3])
-            return hit[1]
+            return hit[1], hit[4]
         n = int(kpts.shape[1])
         tok = torch.empty((n, self.config["loftr_coarse"]["d_model"]), dtype=torch.float32, device=device)
         ws = torch.empty(4096, dtype=torch.uint8, device=device)
         _lib.check(lib.opp_encode_points(ctx, kpts.data_ptr(), bank_c.data_ptr(), n, tok.data_ptr(), ws.data_ptr(),
                                          ws.numel(), stream), "opp_encode_points")
+        # ... and, in the default arithmetic, the image-independent prefix of the coarse transformer (layer 0 on the 3D stream, its
+        # layer-1 projections and KV sums: include/opp_hip.h `opp_object_prefix`; 0 bytes = this configuration has none)
+        prefix = None
+        nb = lib.opp_object_prefix_bytes(ctx, n)
+        if nb:
+            prefix = torch.empty(nb, dtype=torch.uint8, device=device)
+            pws = torch.empty(max(lib.opp_object_prefix_workspace_bytes(ctx, n), 4096), dtype=torch.uint8, device=device)
+            _lib.check(lib.opp_object_prefix(ctx, tok.data_ptr(), n, prefix.data_ptr(), nb, pws.data_ptr(), pws.numel(), stream), "opp_object_prefix")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(device))
-        self._rt["obj"] = (key, tok, src, ev)     # keep the source tensors alive so the key cannot alias
-        return tok
+        self._rt["obj"] = (key, tok, src, ev, prefix)     # keep the source tensors alive so the key cannot alias
+        return tok, prefix
 
     def invalidate_object_cache(self):
         """Drops the cached 3D-point tokens.  Needed only after writes the key cannot see: the cache is keyed on
@@ -760,6 +768,7 @@ class OnePosePlus_model(nn.Module):
                 lib.opp_set_status_flag(ctx, None)
                 lib.opp_set_query_mask(ctx, None)
                 lib.opp_set_keypoint_extent_ref(ctx, None, 0)
+                lib.opp_set_object_prefix(ctx, None, 0)
 
     def _forward_single_impl(self, data, use_token_cache=True, sample=None):
         img = data["query_image"]
@@ -810,7 +819,8 @@ class OnePosePlus_model(nn.Module):
             ws_bytes = lib.opp_forward_coarse_workspace_bytes(ctx, H, W, N)
             ws = self._workspace(ws_bytes, device)
             scale_c = float(H) / float(hc)                                               # coarse_matching.py:222
-            tok3d = self._object_tokens(lib, ctx, kpts, bank_c, device, stream) if use_token_cache else None
+            tok3d, prefix = self._object_tokens(lib, ctx, kpts, bank_c, device, stream) if use_token_cache else (None, None)
+            _lib.check(lib.opp_set_object_prefix(ctx, prefix.data_ptr() if prefix is not None else None, N), "opp_set_object_prefix")
             _lib.check(lib.opp_forward_coarse(
                 ctx, img_c.data_ptr(), H, W, pe.data_ptr() if pe is not None else None, kpts.data_ptr(),
                 bank_c.data_ptr(), tok3d.data_ptr() if tok3d is not None else None, N, scale_c, qscale.data_ptr() if qscale is not None else None,

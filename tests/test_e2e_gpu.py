@@ -593,3 +593,33 @@ def test_skipping_the_unused_fine_map_changes_no_output(overlap):
     fine_on = ops.make_model(cfg, sd, "bf16x3").set_skip_unused_fine_map(True).cuda()
     a, b = ops.run_model(fine_on, data), ops.run_model(ops.make_model(cfg, sd, "bf16x3"), data)
     assert torch.equal(a["expec_f"], b["expec_f"]) and torch.equal(a["mkpts_query_f"], b["mkpts_query_f"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw,n", [((512, 512), 5000), ((96, 136), 777)])
+def test_object_prefix_is_bit_identical(hw, n):
+    """The per-object transformer prefix (include/opp_hip.h `opp_object_prefix`: layer 0 on the 3D stream, its layer-1 projections and
+    KV sums, evaluated once per resident object) changes no bit of any output: BASELINE size and a ragged one (L = 12 x 17 = 204 cells,
+    N = 777: partial 64-token tiles / KV chunks in both streams), coarse-to-fine, against a module that redoes everything per image; the
+    library reports no prefix for the other arithmetics (every layer is then evaluated per image)."""
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_inputs, make_state_dict
+    cfg = default_config(thr=0.0)
+    sd = make_state_dict(cfg, 3)
+    d0 = {k: v.cuda() for k, v in make_inputs(n, hw, 21).items()}
+    cached, plain = ops.make_model(cfg, sd), ops.make_model(cfg, sd)
+    plain.cache_object_tokens = False
+    outs = []
+    for m in (cached, plain, cached):                # third run: the prefix is reused, not recomputed
+        d = dict(d0)
+        with torch.no_grad():
+            m(d)
+        torch.cuda.synchronize()
+        outs.append(d)
+    assert cached._rt["obj"][4] is not None, "the default arithmetic must have a prefix"
+    for o in outs[1:]:
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+            assert torch.equal(outs[0][k], o[k]), k
+    lib, ctx = ops.ctx_of(ops.make_model(cfg, sd, "fp32"))
+    assert lib.opp_object_prefix_bytes(ctx, n) == 0
