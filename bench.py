@@ -470,7 +470,8 @@ def compact_legs(legs):
         out["object_token_cache_off_images_per_s"] = t.get("value")
     f = legs.get("fine_leg") or {}
     if "ms_per_forward" in f:
-        out["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak")}
+        out["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak",
+                                             "fine_branch_path", "match_driven_fine_branch")}
     elif f:
         out["fine"] = f
     tr = legs.get("train_leg") or {}
@@ -942,7 +943,43 @@ def fine_leg(torch, dev, precision, lib, _lib, nsteps=10):
 
     out = {"workload": "full coarse-to-fine forward, %dx%d x %d points, thr %.1f, bank optimised for confident matches "
                        "(tests/golden/%s.npz), single stream" % (hw[0], hw[1], n, thr, name),
-           "matches": M, "ms_per_forward": round(full_ms, 3), "images_per_s": round(1e3 / full_ms, 2)}
+           "matches": M, "ms_per_forward": round(full_ms, 3), "images_per_s": round(1e3 / full_ms, 2),
+           "fine_branch_path": "per-match patches" if M <= model.fine_patch_max_matches else "dense map completed after the match count is known"}
+    # the match-driven fine branch (opp_fine_patches) against the dense fine map inside the fused coarse call, same matches, at the
+    # fixture's own M and at a typical few-hundred-match load (threshold raised until ~300 of the fixture's matches remain)
+    try:
+        mc = torch.sort(d["mconf"].detach().float().cpu()).values
+        cases = [("all", thr)]
+        if M > 320:
+            cases.append(("about_300", float(0.5 * (mc[M - 301] + mc[M - 300]))))
+        md = {}
+        for label, th in cases:
+            cfg_t = default_config(thr=th)
+            row = {"thr": round(th, 6)}
+            for pname, pmax in (("dense_ms", 0), ("patch_ms", 1 << 20)):
+                mt = OnePosePlus_model(cfg_t).eval().set_gemm_precision(precision).set_fine_patch_max_matches(pmax).to(dev)
+                mt.load_state_dict(make_state_dict(cfg_t, wseed), strict=True)
+
+                def fwd_t():
+                    dd = dict(data)
+                    with torch.no_grad():
+                        mt(dd)
+                    return dd
+                for _ in range(3):
+                    dd = fwd_t()
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(nsteps):
+                    fwd_t()
+                torch.cuda.synchronize(dev)
+                row[pname] = round((time.perf_counter() - t) / nsteps * 1e3, 3)
+                row["matches"] = int(dd["mconf"].numel())
+                del mt
+            row["patch_speedup"] = round(row["dense_ms"] / row["patch_ms"], 3)
+            md[label] = row
+        out["match_driven_fine_branch"] = md
+    except Exception as e:
+        out["match_driven_fine_branch"] = {"error": str(e)[:200]}
     fine_ms, _, nl = span(1003)
     if nl > 0 and fine_ms > 0:
         # the fine level is 17.47 MFLOP per match (window transformer, C = 128) -> MFMA-bound as a whole;

@@ -226,6 +226,29 @@ int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const float* ban
              const float* mkpts_c, float base_scale, const float* query_scale, int run_transformer,
              float* expec_f, float* mkpts_f, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Match-driven fine branch (round 5; eval mode, where the folded BatchNorm makes every backbone operator pointwise in its inputs).
+ * The 1/2-resolution half of the FPN fine branch -- layer1_outconv + the bilinear residual, layer1_outconv2 (backbone/resnet.py:154-157):
+ * 78 of the 337 GFLOP of a 512 x 512 forward -- is consumed only through the W x W windows around the M coarse matches
+ * (loftr_module/fine_preprocess.py:41-55).  opp_set_fine_patch_buffers(x1, x2_out) makes the NEXT opp_forward_coarse calls with
+ * feat_f = NULL keep x1 [H/2][W/2][pad32(block_dims[0])] and x2_out [H/4][W/4][pad32(block_dims[1])] (NHWC; element counts from
+ * opp_fine_patch_buffer_floats(ctx, H, W, 0 / 1)) in the caller's buffers and stop the backbone there (NULL, NULL = off).  Once the
+ * match count is known the caller either
+ *   - runs opp_fine_patches: the three convolutions as VALID convolutions over a (W+4)^2 -> (W+2)^2 -> W^2 patch pyramid per match
+ *     (49 MFLOP per match) on the same kernel, weights and K order as the dense maps, written straight into the window tokens of
+ *     loftr_fine, then the fine transformer and FineMatching exactly as opp_fine; or
+ *   - for many matches (break-even ~ 1000 at 512 x 512) completes the dense map with opp_backbone_fine_branch and calls opp_fine.
+ * Both give the bits of the one-call path (tests/test_e2e_gpu.py::test_match_driven_fine_branch_*). */
+int opp_set_fine_patch_buffers(opp_ctx* ctx, float* x1, float* x2_out);
+size_t opp_fine_patch_buffer_floats(const opp_ctx* ctx, int H, int W, int which);
+size_t opp_fine_patches_workspace_bytes(const opp_ctx* ctx, int n_matches);
+int opp_fine_patches(opp_ctx* ctx, const float* x1, const float* x2_out, int H, int W, const float* bank_f, int n_points,
+                     const long long* i_ids, const long long* j_ids, int n_matches, int hc, int wc, const float* mkpts_c,
+                     float base_scale, const float* query_scale, int run_transformer, float* expec_f, float* mkpts_f,
+                     void* workspace, size_t workspace_bytes, void* stream);
+size_t opp_backbone_fine_branch_workspace_bytes(const opp_ctx* ctx, int H, int W);
+int opp_backbone_fine_branch(opp_ctx* ctx, const float* x1, const float* x2_out, int H, int W, float* feat_f, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ---- training step: coarse focal loss (Loss.compute_coarse_loss, src/lightning_model/losses.py:18-55) -------------
  * conf [n] fp32 (the B x N x L confidence matrix, 16-byte aligned), conf_gt [n] int16 (0 / 1; other values are ignored
  * like the reference's `== 1` / `== 0` masks), weight [n] or NULL.

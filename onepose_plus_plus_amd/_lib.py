@@ -86,6 +86,13 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_fine_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_set_fine_patch_buffers": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "opp_fine_patch_buffer_floats": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "opp_fine_patches_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_fine_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "opp_backbone_fine_branch_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "opp_backbone_fine_branch": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_fine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,

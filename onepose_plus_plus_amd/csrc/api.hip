@@ -102,6 +102,8 @@ struct opp_ctx {
   int kpt_extent_n = 0;
   const float* obj_prefix = nullptr;      // opp_set_object_prefix: result of opp_object_prefix for the CURRENT object, or null
   int obj_prefix_n = 0;
+  float* fine_x1 = nullptr;               // opp_set_fine_patch_buffers: caller-owned x1 / x2_out of the CURRENT image (match-driven fine branch)
+  float* fine_x2o = nullptr;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
   float* scratch_h2 = nullptr;     // fp16x2 / bf16x3 pre-split staging (largest weight matrix)
   bool train_packed = false;
@@ -569,8 +571,10 @@ struct SplitKScope {
   ~SplitKScope() { t_splitk_ws = prev; }
 };
 
+// pad < 0: "same" padding ks / 2 (every convolution of the reference); pad = 0: a VALID convolution over Bn small patches (match-driven
+// fine branch: the out-of-image taps are explicit zero rows of the patch)
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
-             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false) {
+             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false, int pad = -1) {
   OppGemm g;
   static const bool splitk_on = !(getenv("OPP_CONV_SPLITK") && getenv("OPP_CONV_SPLITK")[0] == '0');   // A/B switch of the tools
   g.splitk_ws = splitk_on ? t_splitk_ws : nullptr;
@@ -589,7 +593,7 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.Cin = d.cin_pad();
   g.ksize = d.ks;
   g.stride = stride;
-  g.pad = d.ks / 2;
+  g.pad = pad < 0 ? d.ks / 2 : pad;
   g.Hout = (Hin + 2 * g.pad - d.ks) / stride + 1;
   g.Wout = (Win + 2 * g.pad - d.ks) / stride + 1;
   g.W = raw ? d.w_train : d.w;
@@ -662,24 +666,28 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
 }
 
 // phase 0: the whole ResNetFPN_8_2.forward; 1: stem .. layer3 + layer3_outconv (-> feat_c, the coarse map);
-// 2: the FPN fine branch (-> feat_f), which needs only x1, x2 and feat_c of phase 1 -- the coarse level does not depend on it
+// 2: the FPN fine branch (-> feat_f), which needs only x1, x2 and feat_c of phase 1 -- the coarse level does not depend on it;
+// 3: the 1/4-resolution half of that branch only (-> x2_out); 4: its 1/2-resolution half (x1, x2_out -> feat_f; bufs prepared by the caller).
+// x1_ext / x2o_ext: caller-owned buffers that receive x1 / x2_out instead of the workspace (match-driven fine branch).
 int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s, int phase = 0,
-                  BackboneBufs* bufs = nullptr) {
+                  BackboneBufs* bufs = nullptr, float* x1_ext = nullptr, float* x2o_ext = nullptr) {
   OPP_CHECK_ARG(c && c->packed, "backbone: weights not packed");
   OPP_CHECK_ARG(c->bn_packed, "backbone: weights were packed with scope 1 (training step: no BatchNorm-folded convolutions); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone: H,W must be multiples of 8 (got %dx%d)", H, W);
   BackboneBufs local;
   BackboneBufs& b = bufs ? *bufs : local;
-  if (phase != 2) {
+  if (phase == 0 || phase == 1) {
     plan_backbone(c, H, W, a, b);
     if (!a.ok) {
       opp_set_error("backbone: workspace too small");
       return OPP_ERR_WORKSPACE;
     }
+    if (x1_ext) b.x1 = x1_ext;
+    if (x2o_ext) b.x2o = x2o_ext;
   }
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   const int hp = gemm_prec(c->cfg);
-  if (phase != 2) {
+  if (phase == 0 || phase == 1) {
     SplitKScope sk_scope(b.sk1);
     // stem: conv7x7/s2 + BN + ReLU (resnet.py:143): one direct kernel (bf16x3), else im2col + GEMM -- bit-identical
     const char* stem_env = getenv("OPP_STEM_DIRECT");          // A/B switch of the tests / tools
@@ -717,11 +725,14 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
     // FPN (:149-157)
     OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
   }
-  if (phase != 1) {
+  if (phase == 0 || phase == 2 || phase == 3) {
     SplitKScope sk_scope(b.sk2);
     OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
     OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
     OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
+  }
+  if (phase == 0 || phase == 2 || phase == 4) {
+    SplitKScope sk_scope(b.sk2);
     static const int l1out_cfg = getenv("OPP_L1OUT_CFG") ? atoi(getenv("OPP_L1OUT_CFG")) : -1;   // A/B switch (tools): tile of the K = 128 lateral
     OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp, hp == OPP_PREC_BF16X3 ? l1out_cfg : -1));
     OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
@@ -1798,7 +1809,14 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
     // the caller runs no fine stage (fine_matching.enable = False): the fine map is not an output of the forward and nothing
     // downstream reads it, so the FPN fine branch (x1_out; ~44 % of the backbone FLOPs) is not launched
     BackboneBufs bufs;
-    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs));
+    if (ctx->fine_x1 && ctx->fine_x2o) {
+      // match-driven fine branch (opp_set_fine_patch_buffers): x1 and x2_out of this image are kept for opp_fine_patches /
+      // opp_backbone_fine_branch, the 1/2-resolution half of the FPN fine branch is evaluated there, per match or densely
+      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs, ctx->fine_x1, ctx->fine_x2o));
+      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 3, &bufs));
+    } else {
+      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs));
+    }
   } else if (ctx->cfg.fpn_overlap) {
     // The coarse level (tokens, transformer, matcher: many short launches that leave CUs idle) depends only on the
     // coarse map; the FPN fine branch (six chip-filling convolutions, ~40 % of the backbone FLOPs) is needed by the fine
@@ -1870,6 +1888,121 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
 // ----------------------------------------------------------------------------------------
 // fine level
 // ----------------------------------------------------------------------------------------
+namespace {
+// loftr_fine + FineMatching on the window tokens X [M * WW][C] and point tokens f3 = X + M * WW * C (OnePosePlusModel.py:187-201)
+int fine_tail(opp_ctx* ctx, float* X, int M, const float* mkpts_c, float base_scale, const float* qscale, int run_transformer, float* expec_f,
+              float* mkpts_f, Arena& a, hipStream_t s) {
+  const int C = ctx->cfg.fine_d_model, Wwin = ctx->cfg.fine_window, WW = Wwin * Wwin;
+  float* f3 = X + (size_t)M * WW * C;
+  if (run_transformer)
+    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg), nullptr, ctx->cfg.encoder_fusion));
+  const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
+  return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
+}
+
+struct PatchBufs {
+  float *X, *xa, *l1, *u1;
+};
+size_t plan_fine_patches(const opp_ctx* c, int M, Arena& a, PatchBufs& b) {
+  const int C = c->cfg.fine_d_model, W = c->cfg.fine_window, WW = W * W, P9 = W + 4, P7 = W + 2;
+  const int c1 = pad32(c->cfg.block_dims[0]), c2 = pad32(c->cfg.block_dims[1]);
+  b.X = a.f((size_t)M * (WW + 1) * C);
+  b.xa = a.f((size_t)M * P9 * P9 * c1);
+  b.l1 = a.f((size_t)M * P9 * P9 * c2);
+  b.u1 = a.f((size_t)M * P7 * P7 * c2);
+  return a.off;
+}
+}  // namespace
+
+extern "C" int opp_set_fine_patch_buffers(opp_ctx* ctx, float* x1, float* x2_out) {
+  OPP_CHECK_ARG(ctx && ((x1 == nullptr) == (x2_out == nullptr)), "set_fine_patch_buffers: give both buffers or neither");
+  ctx->fine_x1 = x1;
+  ctx->fine_x2o = x2_out;
+  return OPP_OK;
+}
+
+extern "C" size_t opp_fine_patch_buffer_floats(const opp_ctx* ctx, int H, int W, int which) {
+  if (!ctx || H <= 0 || W <= 0) return 0;
+  return which == 0 ? (size_t)(H / 2) * (W / 2) * pad32(ctx->cfg.block_dims[0]) : (size_t)(H / 4) * (W / 4) * pad32(ctx->cfg.block_dims[1]);
+}
+
+extern "C" size_t opp_fine_patches_workspace_bytes(const opp_ctx* ctx, int M) {
+  if (!ctx || M <= 0) return 256;
+  Arena a(nullptr, 0);
+  PatchBufs b;
+  const int WW = ctx->cfg.fine_window * ctx->cfg.fine_window;
+  return opp_align(plan_fine_patches(ctx, M, a, b)) + opp_transformer_workspace_bytes(ctx, 1, M, WW, 1) + 2048;
+}
+
+// Fine level straight from x1 / x2_out of opp_forward_coarse (opp_set_fine_patch_buffers): the three convolutions behind them
+// (layer1_outconv + bilinear residual, layer1_outconv2.0 + folded BatchNorm + LeakyReLU, layer1_outconv2.3; resnet.py:154-157) run as VALID
+// convolutions over a (W+4)^2 -> (W+2)^2 -> W^2 patch pyramid per match, on the same implicit-GEMM kernel, weights and K order as the
+// dense map -- every window value equals the dense one bit for bit -- and land directly in the window-token buffer of loftr_fine
+// (no fine map, no gather).  49 MFLOP per match against 78 GFLOP for the dense half-resolution maps at 512 x 512.
+extern "C" int opp_fine_patches(opp_ctx* ctx, const float* x1, const float* x2_out, int H, int W, const float* bank_f, int n, const long long* i_ids,
+                                const long long* j_ids, int M, int hc, int wc, const float* mkpts_c, float base_scale, const float* qscale,
+                                int run_transformer, float* expec_f, float* mkpts_f, void* ws, size_t ws_bytes, void* stream) {
+  FlagScope flag_scope(ctx);
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(ctx && ctx->packed && x1 && x2_out && bank_f && i_ids && j_ids && mkpts_c && expec_f && mkpts_f && ws, "fine_patches: null argument");
+  OPP_CHECK_ARG(ctx->bn_packed && (ctx->tr_packed || !run_transformer), "fine_patches: weights were packed with scope 1; repack with opp_set_pack_scope(ctx, 0)");
+  OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0 && hc > 0 && wc > 0 && (H / 2) % hc == 0, "fine_patches: bad image / coarse-map size");
+  hipStream_t s = (hipStream_t)stream;
+  const int Hf = H / 2, Wf = W / 2, stride = Hf / hc;
+  const int C = ctx->cfg.fine_d_model, Wwin = ctx->cfg.fine_window, WW = Wwin * Wwin, P9 = Wwin + 4, P7 = Wwin + 2;
+  const int c1 = pad32(ctx->cfg.block_dims[0]), c2 = pad32(ctx->cfg.block_dims[1]);
+  OPP_CHECK_ARG(ctx->l1_out2b.cout_pad() == C, "fine_patches: fine map width %d != fine d_model %d", ctx->l1_out2b.cout_pad(), C);
+  OPP_CHECK_ARG((size_t)M * P9 * P9 * c2 * 4 < (1ull << 31), "fine_patches: too many matches for 32-bit buffer addressing (%d)", M);
+  Arena a(ws, ws_bytes);
+  PatchBufs b;
+  plan_fine_patches(ctx, M, a, b);
+  if (!a.ok) {
+    opp_set_error("fine_patches: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  OppProfScope prof(OPP_PROF_FINE, s, (double)M * ((double)(WW + 1) * C * 4.0 + 5 * 4.0));
+  const int hp = gemm_prec(ctx->cfg);
+  const int org = -(Wwin / 2);                      // window origin relative to the match's fine-map pixel (fine_preprocess.py:41-47: padding W // 2)
+  SplitKScope no_split(nullptr);                    // the dense convolutions these replace are never K-split: same accumulation order
+  // l1 patch = conv1x1(x1 patch) + up2x(x2_out) at the patch pixels (out-of-image pixels: exact zeros)
+  OPP_TRY(opp_fine_patch_gather(x1, Hf, Wf, c1, x2_out, c2, j_ids, M, wc, stride, org - 2, P9, b.xa, b.l1, s));
+  OPP_TRY(run_conv(b.xa, P9, P9, ctx->l1_out, 1, b.l1, OPP_RES_DIRECT, OPP_ACT_NONE, b.l1, s, hp, -1, M, false, 0));
+  // u1 patch = LeakyReLU(BN(conv3x3(l1))) on (W+2)^2 pixels; pixels outside the image are the NEXT convolution's zero padding
+  OPP_TRY(run_conv(b.l1, P9, P9, ctx->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp, -1, M, false, 0));
+  OPP_TRY(opp_patch_zero_oob(b.u1, c2, j_ids, M, wc, stride, org - 1, P7, Hf, Wf, s));
+  // the W x W window of the fine map, written as the match's window tokens; window cells outside the image are the unfold's zero padding
+  OPP_TRY(run_conv(b.u1, P7, P7, ctx->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.X, s, hp, -1, M, false, 0));
+  OPP_TRY(opp_patch_zero_oob(b.X, C, j_ids, M, wc, stride, org, Wwin, Hf, Wf, s));
+  OPP_TRY(opp_fine_points_gather(bank_f, n, i_ids, M, C, b.X + (size_t)M * WW * C, C, s));
+  return fine_tail(ctx, b.X, M, mkpts_c, base_scale, qscale, run_transformer, expec_f, mkpts_f, a, s);
+}
+
+extern "C" size_t opp_backbone_fine_branch_workspace_bytes(const opp_ctx* ctx, int H, int W) {
+  if (!ctx) return 0;
+  return 2 * opp_align((size_t)(H / 2) * (W / 2) * pad32(ctx->cfg.block_dims[1]) * sizeof(float)) + 1024;
+}
+
+// The dense 1/2-resolution half of the FPN fine branch from kept x1 / x2_out (more matches than the patch pyramid pays for): -> feat_f
+extern "C" int opp_backbone_fine_branch(opp_ctx* ctx, const float* x1, const float* x2_out, int H, int W, float* feat_f, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  FlagScope flag_scope(ctx);
+  OPP_CHECK_ARG(ctx && ctx->packed && x1 && x2_out && feat_f && ws, "backbone_fine_branch: null argument");
+  OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone_fine_branch: H,W must be multiples of 8 (got %dx%d)", H, W);
+  Arena a(ws, ws_bytes);
+  BackboneBufs b{};
+  const size_t p2 = (size_t)(H / 2) * (W / 2);
+  b.x1 = const_cast<float*>(x1);
+  b.x2o = const_cast<float*>(x2_out);
+  b.l1 = a.f(p2 * pad32(ctx->cfg.block_dims[1]));
+  b.u1 = a.f(p2 * pad32(ctx->cfg.block_dims[1]));
+  b.sk2 = nullptr;
+  if (!a.ok) {
+    opp_set_error("backbone_fine_branch: workspace too small");
+    return OPP_ERR_WORKSPACE;
+  }
+  return backbone_impl(ctx, nullptr, H, W, nullptr, feat_f, a, (hipStream_t)stream, 4, &b);
+}
+
 extern "C" size_t opp_fine_workspace_bytes(const opp_ctx* ctx, int M) {
   if (!ctx || M <= 0) return 256;
   const int C = ctx->cfg.fine_d_model, WW = ctx->cfg.fine_window * ctx->cfg.fine_window;
@@ -1897,10 +2030,7 @@ extern "C" int opp_fine(opp_ctx* ctx, const float* feat_f, int Hf, int Wf, const
   // whole fine stage as one profiled span; algorithmic bytes: windows + point descriptors gathered, outputs written
   OppProfScope prof(OPP_PROF_FINE, s, (double)M * ((double)(WW + 1) * C * 4.0 + 5 * 4.0));
   OPP_TRY(opp_fine_gather(feat_f, Hf, Wf, C, bank_f, n, i_ids, j_ids, M, wc, Hf / hc, Wwin, C, X, C, f3, C, s));
-  if (run_transformer)
-    OPP_TRY(transformer_impl(ctx->fine, ctx->cfg.fine_is_cross, C, ctx->cfg.fine_nhead, X, M, WW, 1, a, s, gemm_prec(ctx->cfg), nullptr, ctx->cfg.encoder_fusion));
-  const float temp = (float)(1.0 / sqrt((double)C));   // fine_matching.py:82
-  return opp_fine_head(f3, C, X, C, M, Wwin, C, temp, mkpts_c, base_scale, qscale, expec_f, mkpts_f, s);
+  return fine_tail(ctx, X, M, mkpts_c, base_scale, qscale, run_transformer, expec_f, mkpts_f, a, s);
 }
 
 // ----------------------------------------------------------------------------------------

@@ -115,7 +115,123 @@ __global__ __launch_bounds__(256) void fine_head_kernel(const float* __restrict_
   }
 }
 
+// ---- match-driven fine branch (api.hip: opp_fine_patches) -------------------------------------------------------------------
+// In eval mode the last three convolutions of the FPN fine branch (layer1_outconv, layer1_outconv2: backbone/resnet.py:154-157) are
+// consumed only through the W x W windows around the M matches (fine_preprocess.py:41-55), so they are evaluated on a per-match patch
+// pyramid instead of the whole 1/2-resolution map: (W+4)^2 pixels of l1 = conv1x1(x1) + up2x(x2_out) -> (W+2)^2 of u1 -> W^2 of the map.
+// This kernel gathers, per match, the (W+4)^2 x1 rows and the bilinear x2 (align_corners=True) upsampling of x2_out at those pixels
+// (resnet.py:155), with the arithmetic of the GEMM epilogue it replaces (gemm_mfma.hip, OPP_RES_BILINEAR2X) so that the patch path
+// reproduces the dense map bit for bit.  Pixels outside the image are exact zeros (the zero padding of the convolutions that follow).
+__global__ __launch_bounds__(256) void fine_patch_gather_kernel(const float* __restrict__ x1, int Hf, int Wf, int c1,
+                                                                const float* __restrict__ x2o, int Hr, int Wr, int c2, float res_sy,
+                                                                float res_sx, const long long* __restrict__ j_ids, int wc, int stride, int org,
+                                                                int P, float* __restrict__ xa, float* __restrict__ up) {
+  const int m = blockIdx.x;
+  const int j = (int)j_ids[m];
+  const int jy = j / wc, jx = j - jy * wc;
+  const int y0p = jy * stride + org, x0p = jx * stride + org;
+  const int PP = P * P;
+  const int q1 = c1 >> 2, q2 = c2 >> 2;
+  for (int e = threadIdx.x; e < PP * q1; e += blockDim.x) {
+    const int r = e / q1, c = (e - r * q1) * 4;
+    const int py = r / P, px = r - py * P;
+    const int y = y0p + py, x = x0p + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf) v = *reinterpret_cast<const float4*>(x1 + ((size_t)y * Wf + x) * c1 + c);
+    *reinterpret_cast<float4*>(xa + ((size_t)m * PP + r) * c1 + c) = v;
+  }
+  for (int e = threadIdx.x; e < PP * q2; e += blockDim.x) {
+    const int r = e / q2, c = (e - r * q2) * 4;
+    const int py = r / P, px = r - py * P;
+    const int oy = y0p + py, ox = x0p + px;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)oy < (unsigned)Hf && (unsigned)ox < (unsigned)Wf) {
+      // same statements, same order, no FMA contraction: the residual term of the dense convolution's epilogue
+#pragma clang fp contract(off)
+      const float sy = res_sy * (float)oy;
+      const float sx = res_sx * (float)ox;
+      int y0 = (int)sy;
+      if (y0 > Hr - 1) y0 = Hr - 1;
+      int x0 = (int)sx;
+      if (x0 > Wr - 1) x0 = Wr - 1;
+      const int y1 = y0 + (y0 < Hr - 1 ? 1 : 0);
+      const int x1i = x0 + (x0 < Wr - 1 ? 1 : 0);
+      const float wy1 = fminf(fmaxf(sy - (float)y0, 0.f), 1.f);
+      const float wx1 = fminf(fmaxf(sx - (float)x0, 0.f), 1.f);
+      const float wy0 = 1.f - wy1, wx0 = 1.f - wx1;
+      const float4 t0 = *reinterpret_cast<const float4*>(x2o + ((size_t)y0 * Wr + x0) * c2 + c);
+      const float4 t1 = *reinterpret_cast<const float4*>(x2o + ((size_t)y0 * Wr + x1i) * c2 + c);
+      const float4 t2 = *reinterpret_cast<const float4*>(x2o + ((size_t)y1 * Wr + x0) * c2 + c);
+      const float4 t3 = *reinterpret_cast<const float4*>(x2o + ((size_t)y1 * Wr + x1i) * c2 + c);
+      const float a00[4] = {t0.x, t0.y, t0.z, t0.w}, a01[4] = {t1.x, t1.y, t1.z, t1.w};
+      const float a10[4] = {t2.x, t2.y, t2.z, t2.w}, a11[4] = {t3.x, t3.y, t3.z, t3.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float top = wx0 * a00[k] + wx1 * a01[k];
+        const float bot = wx0 * a10[k] + wx1 * a11[k];
+        o[k] = wy0 * top + wy1 * bot;
+      }
+    }
+    *reinterpret_cast<float4*>(up + ((size_t)m * PP + r) * c2 + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// rows of a per-match patch buffer [M][P * P][ld] whose pixel lies outside the image -> exact zeros (what the dense map's consumers
+// read there: the zero padding of the next convolution / of the window unfold).  Interior matches return at once.
+__global__ __launch_bounds__(64) void patch_zero_oob_kernel(float* __restrict__ buf, int ld, const long long* __restrict__ j_ids, int wc, int stride,
+                                                            int org, int P, int Hf, int Wf) {
+  const int m = blockIdx.x;
+  const int j = (int)j_ids[m];
+  const int jy = j / wc, jx = j - jy * wc;
+  const int y0p = jy * stride + org, x0p = jx * stride + org;
+  if (y0p >= 0 && x0p >= 0 && y0p + P <= Hf && x0p + P <= Wf) return;
+  const int q = ld >> 2;
+  for (int e = threadIdx.x; e < P * P * q; e += blockDim.x) {
+    const int r = e / q, c = (e - r * q) * 4;
+    const int py = r / P, px = r - py * P;
+    const int y = y0p + py, x = x0p + px;
+    if (!((unsigned)y < (unsigned)Hf && (unsigned)x < (unsigned)Wf))
+      *reinterpret_cast<float4*>(buf + ((size_t)m * P * P + r) * ld + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// f3 [M][ld3] = bank[:, i_ids[m]]   (the RAW fine bank, quirk q8; the point half of fine_gather_kernel)
+__global__ __launch_bounds__(128) void fine_points_gather_kernel(const float* __restrict__ bank, int n_points, const long long* __restrict__ i_ids, int C,
+                                                                 float* __restrict__ f3, int ld3) {
+  const int m = blockIdx.x;
+  const long long i = i_ids[m];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) f3[(size_t)m * ld3 + c] = bank[(size_t)c * n_points + i];
+}
+
 }  // namespace
+
+int opp_fine_patch_gather(const float* x1, int Hf, int Wf, int c1, const float* x2o, int c2, const long long* j_ids, int M, int wc, int stride, int org, int P,
+                          float* xa, float* up, hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(c1 % 4 == 0 && c2 % 4 == 0 && Hf % 2 == 0 && Wf % 2 == 0, "fine patch gather: channel counts must be multiples of 4, the map size even");
+  const int Hr = Hf / 2, Wr = Wf / 2;
+  // align_corners=True source index scale (in - 1) / (out - 1), as run_conv sets it for the dense convolution (resnet.py:155)
+  const float res_sy = Hf > 1 ? (float)(Hr - 1) / (float)(Hf - 1) : 0.f;
+  const float res_sx = Wf > 1 ? (float)(Wr - 1) / (float)(Wf - 1) : 0.f;
+  hipLaunchKernelGGL(fine_patch_gather_kernel, dim3(M), dim3(256), 0, stream, x1, Hf, Wf, c1, x2o, Hr, Wr, c2, res_sy, res_sx, j_ids, wc, stride, org, P, xa, up);
+  OPP_CHECK_LAUNCH("fine_patch_gather_kernel");
+  return OPP_OK;
+}
+
+int opp_patch_zero_oob(float* buf, int ld, const long long* j_ids, int M, int wc, int stride, int org, int P, int Hf, int Wf, hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(ld % 4 == 0, "patch_zero_oob: row stride must be a multiple of 4");
+  hipLaunchKernelGGL(patch_zero_oob_kernel, dim3(M), dim3(64), 0, stream, buf, ld, j_ids, wc, stride, org, P, Hf, Wf);
+  OPP_CHECK_LAUNCH("patch_zero_oob_kernel");
+  return OPP_OK;
+}
+
+int opp_fine_points_gather(const float* bank, int n_points, const long long* i_ids, int M, int C, float* f3, int ld3, hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  hipLaunchKernelGGL(fine_points_gather_kernel, dim3(M), dim3(128), 0, stream, bank, n_points, i_ids, C, f3, ld3);
+  OPP_CHECK_LAUNCH("fine_points_gather_kernel");
+  return OPP_OK;
+}
 
 int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,
                     const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,

@@ -227,6 +227,10 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
                             float base_scale, const float* qscale, const float* stats, int stats_bm, float* scratch, long long* i_ids, long long* j_ids, float* mconf,
                             float* mkpts_c, float* mkpts_3d, int* count, hipStream_t stream);
 // fine.hip
+int opp_fine_patch_gather(const float* x1, int Hf, int Wf, int c1, const float* x2o, int c2, const long long* j_ids, int M, int wc, int stride, int org, int P,
+                          float* xa, float* up, hipStream_t stream);
+int opp_patch_zero_oob(float* buf, int ld, const long long* j_ids, int M, int wc, int stride, int org, int P, int Hf, int Wf, hipStream_t stream);
+int opp_fine_points_gather(const float* bank, int n_points, const long long* i_ids, int M, int C, float* f3, int ld3, hipStream_t stream);
 int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,
                     const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,
                     float* win, int ldw, float* f3, int ld3, hipStream_t stream);

@@ -181,6 +181,7 @@ class OnePosePlus_model(nn.Module):
         self.score_two_sweep = int(os.environ.get("OPP_SCORE_PATH", "2"))
         self.fpn_overlap = os.environ.get("OPP_FPN_OVERLAP", "1") != "0"
         self.skip_unused_fine_map = os.environ.get("OPP_SKIP_UNUSED_FINE_MAP", "0") == "1"
+        self.fine_patch_max_matches = int(os.environ.get("OPP_FINE_PATCH_MAX", "1000"))
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -245,6 +246,15 @@ class OnePosePlus_model(nn.Module):
         forward does not launch the FPN branch that produces it (~44 % of the backbone FLOPs); every entry of `data` is
         unchanged.  No effect while fine matching is enabled."""
         self.skip_unused_fine_map = bool(on)
+        return self
+
+    def set_fine_patch_max_matches(self, n):
+        """Match-driven fine branch of an eval forward with fine matching enabled (include/opp_hip.h `opp_fine_patches`): the
+        1/2-resolution half of the FPN fine branch (23 % of the forward's FLOPs at 512 x 512) is evaluated on a 9x9 -> 7x7 -> 5x5 patch
+        pyramid around each coarse match (49 MFLOP per match) when there are at most `n` matches, and as the dense map otherwise
+        (default 1000 ~ the measured break-even at 512 x 512; 0 = always the dense map inside the fused coarse call, as before round 5).
+        Bit-identical results either way."""
+        self.fine_patch_max_matches = max(0, int(n))
         return self
 
     def set_score_two_sweep(self, mode):
@@ -769,6 +779,7 @@ class OnePosePlus_model(nn.Module):
                 lib.opp_set_query_mask(ctx, None)
                 lib.opp_set_keypoint_extent_ref(ctx, None, 0)
                 lib.opp_set_object_prefix(ctx, None, 0)
+                lib.opp_set_fine_patch_buffers(ctx, None, None)
 
     def _forward_single_impl(self, data, use_token_cache=True, sample=None):
         img = data["query_image"]
@@ -805,8 +816,17 @@ class OnePosePlus_model(nn.Module):
             pe = self._pe_tokens(hc, wc, device) if self.dense_pos_encoding is not None else None
 
             feat_f = None                                                                # NHWC fine map
-            if cfg["fine_matching"]["enable"] or not getattr(self, "skip_unused_fine_map", False):
+            # match-driven fine branch: the coarse call keeps x1 / x2_out and stops the backbone there; once M is known the windows come
+            # from per-match patches (M <= fine_patch_max_matches) or from the dense map completed afterwards
+            patch_mode = bool(cfg["fine_matching"]["enable"]) and int(getattr(self, "fine_patch_max_matches", 0)) > 0
+            x1_keep = x2o_keep = None
+            if patch_mode:
+                x1_keep = torch.empty(lib.opp_fine_patch_buffer_floats(ctx, H, W, 0), dtype=torch.float32, device=device)
+                x2o_keep = torch.empty(lib.opp_fine_patch_buffer_floats(ctx, H, W, 1), dtype=torch.float32, device=device)
+            elif cfg["fine_matching"]["enable"] or not getattr(self, "skip_unused_fine_map", False):
                 feat_f = torch.empty((hf * wf, dF), dtype=torch.float32, device=device)
+            _lib.check(lib.opp_set_fine_patch_buffers(ctx, x1_keep.data_ptr() if patch_mode else None,
+                                                      x2o_keep.data_ptr() if patch_mode else None), "opp_set_fine_patch_buffers")
             conf = torch.empty((1, N, L), dtype=torch.float32, device=device)
             i_ids = torch.empty(N, dtype=torch.int64, device=device)
             j_ids = torch.empty(N, dtype=torch.int64, device=device)
@@ -851,9 +871,26 @@ class OnePosePlus_model(nn.Module):
                 raise RuntimeError("descriptors3d_db must be [1,%d,%d], got %s" % (dF, N, tuple(bank_f.shape)))
             expec = torch.empty((M, 3), dtype=torch.float32, device=device)
             mk_f = torch.empty((M, 2), dtype=torch.float32, device=device)
+            scale_f = float(H) / float(hf)                                               # fine_matching.py:41
+            if patch_mode and M <= self.fine_patch_max_matches:
+                fws = self._workspace(lib.opp_fine_patches_workspace_bytes(ctx, M), device)
+                _lib.check(lib.opp_fine_patches(
+                    ctx, x1_keep.data_ptr(), x2o_keep.data_ptr(), H, W, bank_f.data_ptr(), N, i_ids.data_ptr(), j_ids.data_ptr(), M, hc, wc,
+                    mk_c.data_ptr(), scale_f, qscale.data_ptr() if qscale is not None else None,
+                    1 if cfg["loftr_fine"]["enable"] else 0, expec.data_ptr(), mk_f.data_ptr(), fws.data_ptr(), fws.numel(), stream),
+                    "opp_fine_patches")
+                if guarded and int(count[1].item()):
+                    return self._range_fallback(data, use_token_cache, sample)
+                data.update({"expec_f": expec, "mkpts_query_f": mk_f})
+                self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, x1_keep, x2o_keep)
+                return
+            if patch_mode:                       # many matches: the dense map from the kept x1 / x2_out, then the window gather
+                feat_f = torch.empty((hf * wf, dF), dtype=torch.float32, device=device)
+                bws = self._workspace(lib.opp_backbone_fine_branch_workspace_bytes(ctx, H, W), device)
+                _lib.check(lib.opp_backbone_fine_branch(ctx, x1_keep.data_ptr(), x2o_keep.data_ptr(), H, W, feat_f.data_ptr(), bws.data_ptr(),
+                                                        bws.numel(), stream), "opp_backbone_fine_branch")
             fws_bytes = lib.opp_fine_workspace_bytes(ctx, M)
             fws = self._workspace(fws_bytes, device)
-            scale_f = float(H) / float(hf)                                               # fine_matching.py:41
             _lib.check(lib.opp_fine(
                 ctx, feat_f.data_ptr(), hf, wf, bank_f.data_ptr(), N, i_ids.data_ptr(), j_ids.data_ptr(), M, hc, wc,
                 mk_c.data_ptr(), scale_f, qscale.data_ptr() if qscale is not None else None,
@@ -863,4 +900,4 @@ class OnePosePlus_model(nn.Module):
                 return self._range_fallback(data, use_token_cache, sample)
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             # keep every tensor whose pointer was handed to the stream alive until here
-            self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, feat_f)
+            self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, feat_f, x1_keep, x2o_keep)

@@ -623,3 +623,53 @@ def test_object_prefix_is_bit_identical(hw, n):
             assert torch.equal(outs[0][k], o[k]), k
     lib, ctx = ops.ctx_of(ops.make_model(cfg, sd, "fp32"))
     assert lib.opp_object_prefix_bytes(ctx, n) == 0
+
+
+def _run_fine_variant(cfg, sd, data, precision, patch_max):
+    from tests import hip_ops as ops
+    m = ops.make_model(cfg, sd, precision).set_fine_patch_max_matches(patch_max)
+    d = {k: v.cuda() for k, v in data.items()}
+    with torch.no_grad():
+        m(d)
+    torch.cuda.synchronize()
+    return d
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_match_driven_fine_branch_is_bit_identical_on_the_highconf_case(precision):
+    """The match-driven fine branch (include/opp_hip.h `opp_fine_patches`: layer1_outconv / layer1_outconv2 as VALID convolutions over a
+    9x9 -> 7x7 -> 5x5 patch pyramid per match, resnet.py:154-157 + fine_preprocess.py:41-55) on the fixture with 1487 confident matches:
+    per-match patches, the dense map completed from the kept x1 / x2_out, and the dense map inside the fused coarse call (the path the
+    reference-generated goldens pin, test_e2e_high_confidence_vs_golden) give the same bits, in every arithmetic."""
+    name = "highconf_512x512_n3000"
+    cfg, sd, data = H.highconf_setup(name)
+    fused = _run_fine_variant(cfg, sd, data, precision, 0)
+    patches = _run_fine_variant(cfg, sd, data, precision, 1 << 20)
+    kept = _run_fine_variant(cfg, sd, data, precision, 1)
+    assert fused["expec_f"].shape[0] > 1000
+    for other in (patches, kept):
+        for k in ("conf_matrix", "i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+            assert torch.equal(fused[k], other[k]), (precision, k)
+
+
+@pytest.mark.parametrize("window", [3, 5, 7])
+@pytest.mark.parametrize("hw", [(64, 96), (136, 104)])
+def test_match_driven_fine_branch_at_the_image_border(hw, window):
+    """border_rm = 0 and thr = 0: matches on the first / last coarse rows and columns, whose (W+4)^2 / (W+2)^2 patches and W^2 windows
+    reach outside the image -- the out-of-image pixels must be the zero padding of the dense convolutions / of the window unfold
+    (resnet.py:17-19, fine_preprocess.py:41-47).  Bit-identical to the dense path for window sizes 3 / 5 / 7."""
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_inputs, make_state_dict
+    cfg = default_config(thr=0.0)
+    cfg["coarse_matching"]["border_rm"] = 0
+    cfg["loftr_fine"]["window_size"] = window
+    sd = make_state_dict(cfg, 11)
+    n = (hw[0] // 8) * (hw[1] // 8) + 40              # more points than cells: every cell can be somebody's mutual nearest neighbour
+    data = make_inputs(n, hw, 5)
+    fused = _run_fine_variant(cfg, sd, data, None, 0)
+    patches = _run_fine_variant(cfg, sd, data, None, 1 << 20)
+    wc = hw[1] // 8
+    jy, jx = fused["j_ids"] // wc, fused["j_ids"] % wc
+    assert int(((jy == 0) | (jx == 0) | (jy == hw[0] // 8 - 1) | (jx == wc - 1)).sum()) > 0, "no border match: the case tests nothing"
+    for k in ("i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
+        assert torch.equal(fused[k], patches[k]), k

@@ -593,6 +593,6 @@ def test_training_graph_with_a_frozen_pretrained_backbone(tmp_path):
     # the next eval forward repacks for inference (scope 0 was kept) and runs
     model.eval()
     with torch.no_grad():
-        e = {k: v[:1] for k, v in d.items() if k != "conf_matrix_gt"}
+        e = {k: d[k][:1] for k in data if k != "conf_matrix_gt"}
         model(e)
     assert torch.isfinite(e["conf_matrix"]).all()

@@ -66,7 +66,8 @@ def split_w(lib, w, cfgs, prec, s):
     if prec == 2:
         w2 = torch.empty(w.numel() // 2 * 3, device="cuda")
         _lib.check(lib.opp_pack_b3(w.data_ptr(), w2.data_ptr(), w.numel(), s), "pack_b3")
-        return w2, sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 20, 22, 25, 26, 30)] + [-1]))
+        ok = (0, 1, 2, 10, 20, 22, 25, 26, 30) + ((140,) if os.environ.get("OPP_ABLATE") else ())     # 140: the tuning library's 128 x 192 tile
+        return w2, sorted(set([c for c in cfgs if c in ok] + [-1]))
     return w, cfgs
 
 
