@@ -374,6 +374,17 @@ int opp_fine_window_gather_backward(const float* grad_windows, int B, int Hf, in
                                     const long long* j_ids, int n_matches, int hc, int wc, int window, float* grad_feat_f,
                                     void* stream);
 
+/* Ground-truth matrices of one training sample, formed on the device from the k assignment pairs
+ * (OnePosePlusDataset.build_assignmatrix, src/datasets/OnePosePlus_dataset.py:174-236; the loader builds 229 MB per sample on the host
+ * at N = 7000).  kp2d_coarse / kp2d_fine [n2d][2] fp32; assign [2][k] int64 (row 0: 2D keypoint index, row 1: padded 3D point index);
+ * scale_x / scale_y = query_img_scale[1] / [0].  conf_gt [N][L] int16 (zeroed here, 1 at the pairs), fine_loc_gt [N][L][2] fp32 (-50
+ * filled here, the fine keypoint at the pairs; 16-byte aligned); pairs with a 3D index >= N or j > L are dropped like upstream, of
+ * duplicate (i, j) pairs the last one wins (CPU index_put).  keys: k int64 of scratch.  *status (device int): bit 0 = an index upstream
+ * raises IndexError on (skipped here), bit 1 = duplicate pairs seen (upstream logs "Keypoints duplicate!"). */
+int opp_build_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int n2d, const long long* assign, int k, int N, int L,
+                           int w_c, float scale_x, float scale_y, float coarse_scale, short* conf_gt, float* fine_loc_gt,
+                           long long* keys, int* status, void* stream);
+
 /* ---- building blocks (exported for stage-level parity tests and tuning) ------------------ */
 /* NHWC convolution as implicit GEMM on the MFMA.  x [Hin][Win][cin_pad], cin_pad = cin rounded up to 32 (pad
  * channels zero); w_packed [cout_pad][opp_conv_packed_k(cin, ks)] (from opp_pack_conv_weight with the same cin:

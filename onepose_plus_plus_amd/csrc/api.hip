@@ -565,20 +565,35 @@ namespace {
 // split-K scratch of the convolutions this host thread is enqueuing (backbone_impl sets it per stream branch; null = never split)
 constexpr size_t kSplitKScratchFloats = (size_t)4 << 20;      // 4 slices of <= 64 tiles of 128 x 128
 thread_local float* t_splitk_ws = nullptr;
+thread_local size_t t_splitk_ws_floats = 0;
 struct SplitKScope {
   float* prev;
-  explicit SplitKScope(float* ws) : prev(t_splitk_ws) { t_splitk_ws = ws; }
-  ~SplitKScope() { t_splitk_ws = prev; }
+  size_t prev_floats;
+  explicit SplitKScope(float* ws, size_t floats = kSplitKScratchFloats) : prev(t_splitk_ws), prev_floats(t_splitk_ws_floats) {
+    t_splitk_ws = ws;
+    t_splitk_ws_floats = ws ? floats : 0;
+  }
+  ~SplitKScope() {
+    t_splitk_ws = prev;
+    t_splitk_ws_floats = prev_floats;
+  }
 };
+// would the DENSE convolution d over `pixels` output pixels run as K slices (opp_gemm_launch_cfg: <= 64 tiles of 128 x 128 under >= 32
+// K chunks, bf16x3, the A/B switch OPP_CONV_SPLITK aside)?
+bool conv_splits_by_shape(const ConvDesc& d, size_t pixels, int prec) {
+  const long long tiles128 = (long long)((pixels + 127) / 128) * ((d.cout_pad() + 127) / 128);
+  return prec == OPP_PREC_BF16X3 && tiles128 <= 64 && d.k_len() / 32 >= 32;
+}
 
 // pad < 0: "same" padding ks / 2 (every convolution of the reference); pad = 0: a VALID convolution over Bn small patches (match-driven
 // fine branch: the out-of-image taps are explicit zero rows of the patch)
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
-             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false, int pad = -1) {
+             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false, int pad = -1, int splitk_force = -1) {
   OppGemm g;
   static const bool splitk_on = !(getenv("OPP_CONV_SPLITK") && getenv("OPP_CONV_SPLITK")[0] == '0');   // A/B switch of the tools
   g.splitk_ws = splitk_on ? t_splitk_ws : nullptr;
-  g.splitk_ws_floats = g.splitk_ws ? kSplitKScratchFloats : 0;
+  g.splitk_ws_floats = g.splitk_ws ? t_splitk_ws_floats : 0;
+  g.splitk_force = splitk_force;
   g.nonfinite = t_status_flag;
   g.tile_policy = t_tile_policy;
   g.conv = 1;
@@ -1805,18 +1820,15 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
   size_t mark = a.off;
   const int hc = H / 8, wc = W / 8, L = hc * wc, C = ctx->cfg.coarse_d_model;
   bool forked = false;
-  if (!feat_f) {
+  // what runs beside the coarse level: the whole FPN fine branch (-> feat_f), or -- match-driven fine branch, opp_set_fine_patch_buffers --
+  // only its 1/4-resolution half (-> x2_out; x1 / x2_out land in the caller's buffers), or nothing (feat_f = NULL: the fine map is dead)
+  const bool keep_inputs = !feat_f && ctx->fine_x1 && ctx->fine_x2o;
+  const int side_phase = feat_f ? 2 : (keep_inputs ? 3 : 0);
+  if (side_phase == 0) {
     // the caller runs no fine stage (fine_matching.enable = False): the fine map is not an output of the forward and nothing
     // downstream reads it, so the FPN fine branch (x1_out; ~44 % of the backbone FLOPs) is not launched
     BackboneBufs bufs;
-    if (ctx->fine_x1 && ctx->fine_x2o) {
-      // match-driven fine branch (opp_set_fine_patch_buffers): x1 and x2_out of this image are kept for opp_fine_patches /
-      // opp_backbone_fine_branch, the 1/2-resolution half of the FPN fine branch is evaluated there, per match or densely
-      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs, ctx->fine_x1, ctx->fine_x2o));
-      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 3, &bufs));
-    } else {
-      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs));
-    }
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs));
   } else if (ctx->cfg.fpn_overlap) {
     // The coarse level (tokens, transformer, matcher: many short launches that leave CUs idle) depends only on the
     // coarse map; the FPN fine branch (six chip-filling convolutions, ~40 % of the backbone FLOPs) is needed by the fine
@@ -1840,14 +1852,14 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
       ctx->ev_join = ej;
     }
     BackboneBufs bufs;
-    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 1, &bufs));
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 1, &bufs, keep_inputs ? ctx->fine_x1 : nullptr, keep_inputs ? ctx->fine_x2o : nullptr));
     mark = a.off;                                    // the backbone buffers stay alive until the join
     // fork: if the dependency cannot be expressed the fine branch runs on the caller's stream (same kernels, no overlap)
     const bool fork_ok = hipEventRecord(ctx->ev_fork, s) == hipSuccess && hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0) == hipSuccess;
     if (!fork_ok) {
-      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, 2, &bufs));
+      OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s, side_phase, &bufs));
     } else {
-      const int rc = backbone_impl(ctx, image, H, W, feat_c, feat_f, a, ctx->side_stream, 2, &bufs);
+      const int rc = backbone_impl(ctx, image, H, W, feat_c, feat_f, a, ctx->side_stream, side_phase, &bufs);
       if (hipEventRecord(ctx->ev_join, ctx->side_stream) != hipSuccess) {
         // the join cannot be expressed as an event: wait for the side stream on the host before anything reuses its buffers
         (void)hipStreamSynchronize(ctx->side_stream);
@@ -1860,6 +1872,10 @@ extern "C" int opp_forward_coarse(opp_ctx* ctx, const float* image, int H, int W
         }
       }
     }
+  } else if (keep_inputs) {
+    BackboneBufs bufs;
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 1, &bufs, ctx->fine_x1, ctx->fine_x2o));
+    OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, nullptr, a, s, 3, &bufs));
   } else {
     OPP_TRY(backbone_impl(ctx, image, H, W, feat_c, feat_f, a, s));
   }
@@ -1901,7 +1917,8 @@ int fine_tail(opp_ctx* ctx, float* X, int M, const float* mkpts_c, float base_sc
 }
 
 struct PatchBufs {
-  float *X, *xa, *l1, *u1;
+  float *X, *xa, *l1, *u1, *sk;
+  size_t sk_floats;
 };
 size_t plan_fine_patches(const opp_ctx* c, int M, Arena& a, PatchBufs& b) {
   const int C = c->cfg.fine_d_model, W = c->cfg.fine_window, WW = W * W, P9 = W + 4, P7 = W + 2;
@@ -1910,6 +1927,10 @@ size_t plan_fine_patches(const opp_ctx* c, int M, Arena& a, PatchBufs& b) {
   b.xa = a.f((size_t)M * P9 * P9 * c1);
   b.l1 = a.f((size_t)M * P9 * P9 * c2);
   b.u1 = a.f((size_t)M * P7 * P7 * c2);
+  // K-slice partials, for the (small) images whose dense convolutions run split: 4 slices of the larger patch output
+  const size_t r1 = (size_t)M * P7 * P7 * c2, r2 = (size_t)M * WW * C;
+  b.sk_floats = 4 * (r1 > r2 ? r1 : r2);
+  b.sk = a.f(b.sk_floats);
   return a.off;
 }
 }  // namespace
@@ -1963,15 +1984,19 @@ extern "C" int opp_fine_patches(opp_ctx* ctx, const float* x1, const float* x2_o
   OppProfScope prof(OPP_PROF_FINE, s, (double)M * ((double)(WW + 1) * C * 4.0 + 5 * 4.0));
   const int hp = gemm_prec(ctx->cfg);
   const int org = -(Wwin / 2);                      // window origin relative to the match's fine-map pixel (fine_preprocess.py:41-47: padding W // 2)
-  SplitKScope no_split(nullptr);                    // the dense convolutions these replace are never K-split: same accumulation order
+  // same accumulation order as the dense map: a layer runs as K slices here exactly when its dense convolution over Hf x Wf pixels does
+  // (small images only; at 512 x 512 neither does)
+  SplitKScope sk_scope(b.sk, b.sk_floats);
+  const size_t dense_px = (size_t)Hf * Wf;
+  const int split_a = conv_splits_by_shape(ctx->l1_out2a, dense_px, hp) ? 1 : 0, split_b = conv_splits_by_shape(ctx->l1_out2b, dense_px, hp) ? 1 : 0;
   // l1 patch = conv1x1(x1 patch) + up2x(x2_out) at the patch pixels (out-of-image pixels: exact zeros)
   OPP_TRY(opp_fine_patch_gather(x1, Hf, Wf, c1, x2_out, c2, j_ids, M, wc, stride, org - 2, P9, b.xa, b.l1, s));
-  OPP_TRY(run_conv(b.xa, P9, P9, ctx->l1_out, 1, b.l1, OPP_RES_DIRECT, OPP_ACT_NONE, b.l1, s, hp, -1, M, false, 0));
+  OPP_TRY(run_conv(b.xa, P9, P9, ctx->l1_out, 1, b.l1, OPP_RES_DIRECT, OPP_ACT_NONE, b.l1, s, hp, -1, M, false, 0, 0));   // (K = 4 chunks: never split)
   // u1 patch = LeakyReLU(BN(conv3x3(l1))) on (W+2)^2 pixels; pixels outside the image are the NEXT convolution's zero padding
-  OPP_TRY(run_conv(b.l1, P9, P9, ctx->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp, -1, M, false, 0));
+  OPP_TRY(run_conv(b.l1, P9, P9, ctx->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp, -1, M, false, 0, split_a));
   OPP_TRY(opp_patch_zero_oob(b.u1, c2, j_ids, M, wc, stride, org - 1, P7, Hf, Wf, s));
   // the W x W window of the fine map, written as the match's window tokens; window cells outside the image are the unfold's zero padding
-  OPP_TRY(run_conv(b.u1, P7, P7, ctx->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.X, s, hp, -1, M, false, 0));
+  OPP_TRY(run_conv(b.u1, P7, P7, ctx->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.X, s, hp, -1, M, false, 0, split_b));
   OPP_TRY(opp_patch_zero_oob(b.X, C, j_ids, M, wc, stride, org, Wwin, Hf, Wf, s));
   OPP_TRY(opp_fine_points_gather(bank_f, n, i_ids, M, C, b.X + (size_t)M * WW * C, C, s));
   return fine_tail(ctx, b.X, M, mkpts_c, base_scale, qscale, run_transformer, expec_f, mkpts_f, a, s);
@@ -1979,7 +2004,7 @@ extern "C" int opp_fine_patches(opp_ctx* ctx, const float* x1, const float* x2_o
 
 extern "C" size_t opp_backbone_fine_branch_workspace_bytes(const opp_ctx* ctx, int H, int W) {
   if (!ctx) return 0;
-  return 2 * opp_align((size_t)(H / 2) * (W / 2) * pad32(ctx->cfg.block_dims[1]) * sizeof(float)) + 1024;
+  return 2 * opp_align((size_t)(H / 2) * (W / 2) * pad32(ctx->cfg.block_dims[1]) * sizeof(float)) + opp_align(kSplitKScratchFloats * sizeof(float)) + 1024;
 }
 
 // The dense 1/2-resolution half of the FPN fine branch from kept x1 / x2_out (more matches than the patch pyramid pays for): -> feat_f
@@ -1995,7 +2020,7 @@ extern "C" int opp_backbone_fine_branch(opp_ctx* ctx, const float* x1, const flo
   b.x2o = const_cast<float*>(x2_out);
   b.l1 = a.f(p2 * pad32(ctx->cfg.block_dims[1]));
   b.u1 = a.f(p2 * pad32(ctx->cfg.block_dims[1]));
-  b.sk2 = nullptr;
+  b.sk2 = a.f(kSplitKScratchFloats);      // small images: these convolutions run as K slices, as inside the one-call path
   if (!a.ok) {
     opp_set_error("backbone_fine_branch: workspace too small");
     return OPP_ERR_WORKSPACE;
@@ -2235,6 +2260,13 @@ extern "C" size_t opp_dual_softmax_forward_workspace_bytes(int B, int N, int L) 
 extern "C" int opp_dual_softmax_forward(const float* sim, int B, int N, int L, float* lse_row, float* lse_col, float* conf, void* ws, size_t ws_bytes,
                                         void* stream) {
   return opp_dual_softmax_lse(sim, B, N, L, lse_row, lse_col, conf, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int opp_build_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int n2d, const long long* assign, int k, int N, int L, int w_c,
+                                      float scale_x, float scale_y, float coarse_scale, short* conf_gt, float* fine_loc_gt, long long* keys, int* status,
+                                      void* stream) {
+  return opp_assignmatrix(kp2d_coarse, kp2d_fine, n2d, assign, k, N, L, w_c, scale_x, scale_y, coarse_scale, conf_gt, fine_loc_gt, keys, status,
+                          (hipStream_t)stream);
 }
 
 extern "C" int opp_fine_window_gather(const float* feat_f, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids, int n_matches,

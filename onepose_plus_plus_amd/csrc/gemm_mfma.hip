@@ -1208,7 +1208,8 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     const long long tiles128 = (long long)opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
     const int nkc = g.K / 32;
     const size_t need = (size_t)kSplits * g.M * g.ldc;
-    if (tiles128 <= 64 && nkc >= 32 && g.splitk_ws_floats >= need && need < (1ull << 31)) {
+    const bool by_shape = tiles128 <= 64 && nkc >= 32;
+    if ((g.splitk_force > 0 || (g.splitk_force < 0 && by_shape)) && nkc >= kSplits && g.splitk_ws_floats >= need && need < (1ull << 31)) {
       OppGemm gs = g;
       gs.C = g.splitk_ws;
       gs.k_splits = kSplits;

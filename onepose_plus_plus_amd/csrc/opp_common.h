@@ -158,6 +158,9 @@ struct OppGemm {
   // four-wave ones -- and a fixed-order reduction applies bias / residual / activation.  The decision depends on the shape only.
   float* splitk_ws = nullptr;
   size_t splitk_ws_floats = 0;
+  // -1: split by shape (above); 0: never; 1: always when the scratch allows.  The match-driven fine branch evaluates a layer on a few
+  // patch rows and takes the decision the DENSE convolution of the same layer takes, so that both accumulate in the same order.
+  int splitk_force = -1;
 };
 
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream);

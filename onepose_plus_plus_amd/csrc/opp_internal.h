@@ -205,6 +205,8 @@ int opp_fine_gather_batch(const float* feat, int Hf, int Wf, int C, const long l
                           float* win, hipStream_t stream);
 int opp_fine_scatter_batch(const float* gwin, int B, int Hf, int Wf, int C, const long long* b_ids, const long long* j_ids, int M, int wc, int stride,
                            int Wwin, float* dfeat, hipStream_t stream);
+int opp_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int n2d, const long long* assign, int k, int N, int L, int w_c, float scale_x,
+                     float scale_y, float coarse_scale, short* conf_gt, float* fine_loc_gt, long long* keys, int* status, hipStream_t stream);
 // kpt.hip
 int opp_kpt_stats(const float* kpts, int n, float* stats, hipStream_t stream);
 int opp_kpt_encode(const float* kpts, const float* stats, const float* bank, int n, const float* const* wt,

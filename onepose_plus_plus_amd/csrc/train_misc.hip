@@ -314,3 +314,85 @@ int opp_fine_scatter_batch(const float* gwin, int B, int Hf, int Wf, int C, cons
   OPP_CHECK_LAUNCH("fine_scatter_batch_kernel");
   return OPP_OK;
 }
+
+
+// ----------------------------------------------------------------------------------------------------------------------------
+// Ground-truth matrices of one training sample on the device: OnePosePlusDataset.build_assignmatrix
+// (/root/reference/src/datasets/OnePosePlus_dataset.py:174-236).  The loader builds conf_matrix_gt [N][L] int16 and
+// fine_location_matrix_gt [N][L][2] fp32 (-50 filled) on the host -- 229 MB per sample at N = 7000 -- from k <= a few thousand
+// (2D keypoint, 3D point) pairs; here only the pairs travel and the matrices are formed where they are consumed.
+//   key[t] = i * L + j of pair t, or -1 when the reference drops it (padded 3D index >= N, j > L); status bit 0: an index the
+//   reference would raise IndexError on (j == L, indices out of range), bit 1: duplicate (i, j) pairs ("Keypoints duplicate!").
+// ----------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void assign_keys_kernel(const float* __restrict__ kc, int n2d, const long long* __restrict__ assign, int k, int N, int L,
+                                                          int wc, float sx, float sy, float cs, long long* __restrict__ keys, int* __restrict__ status) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= k) return;
+  long long kp = assign[t], i = assign[(size_t)k + t];
+  long long key = -1;
+  if (i < N) {                                     // valid = assign_matrix[1] < self.shape3d  (:195-196)
+    if (kp < 0) kp += n2d;                         // torch indexing wraps negative indices once
+    if (i < 0) i += N;
+    if (kp < 0 || kp >= n2d || i < 0) {
+      atomicOr(status, 1);
+    } else {
+      // keypoints2D_coarse_selected / query_img_scale[[1, 0]] * coarse_scale, rounded half to even (:205-212)
+      const float x = rintf(kc[2 * kp] / sx * cs), y = rintf(kc[2 * kp + 1] / sy * cs);
+      long long j = (long long)(y * (float)wc + x);   // (:219-223)
+      if (!(j > L)) {                              // invalid_mask = j_ids > conf_matrix.shape[1]  (:225): j == L survives the mask ...
+        if (j < 0) j += L;
+        if (j < 0 || j >= L) atomicOr(status, 1);   // ... and is an IndexError upstream
+        else key = i * (long long)L + j;
+      }
+    }
+  }
+  keys[t] = key;
+}
+
+// index_put with repeated indices on the CPU keeps the LAST value: pair t writes unless a later pair has the same (i, j)
+__global__ __launch_bounds__(256) void assign_scatter_kernel(const float* __restrict__ kf, int n2d, const long long* __restrict__ assign, int k,
+                                                             const long long* __restrict__ keys, short* __restrict__ conf, float* __restrict__ floc,
+                                                             int* __restrict__ status) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= k) return;
+  const long long key = keys[t];
+  if (key < 0) return;
+  for (int u = t + 1; u < k; ++u)
+    if (keys[u] == key) {
+      atomicOr(status, 2);
+      return;
+    }
+  long long kp = assign[t];
+  if (kp < 0) kp += n2d;
+  conf[key] = 1;
+  floc[2 * key] = kf[2 * kp];
+  floc[2 * key + 1] = kf[2 * kp + 1];
+}
+
+__global__ __launch_bounds__(256) void fill4_kernel(float4* __restrict__ out, size_t n4, float v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) out[i] = make_float4(v, v, v, v);
+}
+
+}  // namespace
+
+int opp_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int n2d, const long long* assign, int k, int N, int L, int w_c, float scale_x,
+                     float scale_y, float coarse_scale, short* conf_gt, float* fine_loc_gt, long long* keys, int* status, hipStream_t stream) {
+  OPP_CHECK_ARG(conf_gt && fine_loc_gt && N > 0 && L > 0 && w_c > 0 && k >= 0 && n2d >= 0, "build_assignmatrix: bad argument");
+  OPP_CHECK_ARG(k == 0 || (kp2d_coarse && kp2d_fine && assign && keys && status), "build_assignmatrix: null pair data");
+  OPP_CHECK_ARG((reinterpret_cast<uintptr_t>(fine_loc_gt) & 15) == 0 && ((size_t)N * L * 2) % 4 == 0, "build_assignmatrix: fine_location_matrix must be 16-byte aligned");
+  if (hipMemsetAsync(conf_gt, 0, (size_t)N * L * sizeof(short), stream) != hipSuccess || (status && hipMemsetAsync(status, 0, sizeof(int), stream) != hipSuccess)) {
+    opp_set_error("build_assignmatrix: memset failed");
+    return OPP_ERR_LAUNCH;
+  }
+  const size_t n4 = (size_t)N * L * 2 / 4;
+  hipLaunchKernelGGL(fill4_kernel, dim3(grid_for(n4)), dim3(256), 0, stream, reinterpret_cast<float4*>(fine_loc_gt), n4, -50.0f);
+  if (k > 0) {
+    hipLaunchKernelGGL(assign_keys_kernel, dim3(opp_cdiv(k, 256)), dim3(256), 0, stream, kp2d_coarse, n2d, assign, k, N, L, w_c, scale_x, scale_y, coarse_scale,
+                       keys, status);
+    hipLaunchKernelGGL(assign_scatter_kernel, dim3(opp_cdiv(k, 256)), dim3(256), 0, stream, kp2d_fine, n2d, assign, k, keys, conf_gt, fine_loc_gt, status);
+  }
+  OPP_CHECK_LAUNCH("build_assignmatrix kernels");
+  return OPP_OK;
+}

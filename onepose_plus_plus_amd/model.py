@@ -182,6 +182,7 @@ class OnePosePlus_model(nn.Module):
         self.fpn_overlap = os.environ.get("OPP_FPN_OVERLAP", "1") != "0"
         self.skip_unused_fine_map = os.environ.get("OPP_SKIP_UNUSED_FINE_MAP", "0") == "1"
         self.fine_patch_max_matches = int(os.environ.get("OPP_FINE_PATCH_MAX", "1000"))
+        self.fine_patch_pixels_per_match = 64      # patches only while M <= fine-map pixels / this (0 = no such rule; tests force the path)
         self._reset_runtime()
 
     def set_gemm_precision(self, name):
@@ -251,9 +252,11 @@ class OnePosePlus_model(nn.Module):
     def set_fine_patch_max_matches(self, n):
         """Match-driven fine branch of an eval forward with fine matching enabled (include/opp_hip.h `opp_fine_patches`): the
         1/2-resolution half of the FPN fine branch (23 % of the forward's FLOPs at 512 x 512) is evaluated on a 9x9 -> 7x7 -> 5x5 patch
-        pyramid around each coarse match (49 MFLOP per match) when there are at most `n` matches, and as the dense map otherwise
-        (default 1000 ~ the measured break-even at 512 x 512; 0 = always the dense map inside the fused coarse call, as before round 5).
-        Bit-identical results either way."""
+        pyramid around each coarse match (49 MFLOP per match) when there are at most min(n, fine-map pixels / 64) matches, and as the
+        dense map otherwise (default 1000 ~ the measured break-even at 512 x 512; 0 = always the dense map inside the fused coarse
+        call, as before round 5).  The match count is only known after the coarse level, so the forward either keeps x1 / x2_out and
+        decides then, or -- when the PREVIOUS forward of this module had more matches than the limit (consecutive frames of one object
+        look alike) -- runs the dense branch inside the coarse call, beside the coarse level, as before.  Bit-identical results either way."""
         self.fine_patch_max_matches = max(0, int(n))
         return self
 
@@ -818,7 +821,12 @@ class OnePosePlus_model(nn.Module):
             feat_f = None                                                                # NHWC fine map
             # match-driven fine branch: the coarse call keeps x1 / x2_out and stops the backbone there; once M is known the windows come
             # from per-match patches (M <= fine_patch_max_matches) or from the dense map completed afterwards
-            patch_mode = bool(cfg["fine_matching"]["enable"]) and int(getattr(self, "fine_patch_max_matches", 0)) > 0
+            patch_limit = int(getattr(self, "fine_patch_max_matches", 0))
+            if int(getattr(self, "fine_patch_pixels_per_match", 64)) > 0:
+                patch_limit = min(patch_limit, (hf * wf) // int(self.fine_patch_pixels_per_match))
+            self._rt["fine_path"] = "dense map inside the coarse call"
+            last_m = self._rt.get("last_matches")
+            patch_mode = bool(cfg["fine_matching"]["enable"]) and patch_limit > 0 and (last_m is None or last_m <= patch_limit)
             x1_keep = x2o_keep = None
             if patch_mode:
                 x1_keep = torch.empty(lib.opp_fine_patch_buffer_floats(ctx, H, W, 0), dtype=torch.float32, device=device)
@@ -851,6 +859,7 @@ class OnePosePlus_model(nn.Module):
                 M, flag = count.tolist()                                                 # the one D2H sync
             if flag:
                 return self._range_fallback(data, use_token_cache, sample)
+            self._rt["last_matches"] = M
             b_ids = torch.zeros(M, dtype=torch.int64, device=device)
             data.update({
                 "conf_matrix": conf,
@@ -872,7 +881,9 @@ class OnePosePlus_model(nn.Module):
             expec = torch.empty((M, 3), dtype=torch.float32, device=device)
             mk_f = torch.empty((M, 2), dtype=torch.float32, device=device)
             scale_f = float(H) / float(hf)                                               # fine_matching.py:41
-            if patch_mode and M <= self.fine_patch_max_matches:
+            if patch_mode:
+                self._rt["fine_path"] = "per-match patches" if M <= patch_limit else "dense map completed after the match count is known"
+            if patch_mode and M <= patch_limit:
                 fws = self._workspace(lib.opp_fine_patches_workspace_bytes(ctx, M), device)
                 _lib.check(lib.opp_fine_patches(
                     ctx, x1_keep.data_ptr(), x2o_keep.data_ptr(), H, W, bank_f.data_ptr(), N, i_ids.data_ptr(), j_ids.data_ptr(), M, hc, wc,

@@ -66,3 +66,30 @@ LOSS_CASES = {
 }
 LOSS_CONFIG = {"coarse_type": "focal", "coarse_weight": 1.0, "fine_type": "l2_with_std", "fine_weight": 0.81,
                "focal_alpha": 0.5, "focal_gamma": 2.0, "pos_weight": 1.0, "neg_weight": 1.0, "fine_correct_thr": 1.0}   # train.yaml:129-144
+
+
+# ---- device-side ground-truth builder (OnePosePlus_dataset.py:174-236); fixtures: gen_assignmatrix_golden.py ------------------
+# name -> (shape3d N, h_c, w_c, number of 2D keypoints, k pairs, (scale_h, scale_w), seed)
+ASSIGN_CASES = {
+    "assignmatrix_n7000_64x64": (7000, 64, 64, 2500, 3000, (1.25, 0.875), 3),      # training pad size (train.yaml:194), 512 x 512 image
+    "assignmatrix_n300_12x16": (300, 12, 16, 150, 400, (1.0, 1.0), 4),             # small: many duplicate (i, j) pairs, ragged L
+}
+
+
+def make_assign_inputs(case):
+    """-> keypoints2D_coarse [n2d, 2], keypoints2D_fine [n2d, 2], assign_matrix [2, k] (float, as read_anno2d returns it), meta.
+    Keypoints in original-image pixels (x, y); some pairs point at padded 3D indices (>= shape3d, dropped upstream), some repeat an
+    earlier (2D keypoint, 3D point) pair or hit the same cell from another keypoint (last write wins), values on the .5 rounding edge
+    included (half-to-even)."""
+    import torch
+    N, hc, wc, n2d, k, scale, seed = case
+    g = torch.Generator().manual_seed(seed)
+    sc = torch.tensor(scale, dtype=torch.float)
+    W, H = wc * 8 * scale[1], hc * 8 * scale[0]
+    kc = torch.rand(n2d, 2, generator=g) * torch.tensor([W - 8.0 * scale[1], H - 8.0 * scale[0]])
+    kc[: n2d // 8] = (torch.floor(kc[: n2d // 8] / (8.0 * sc[[1, 0]])) + 0.5) * 8.0 * sc[[1, 0]]     # exact .5 cells after rescaling
+    kf = kc + (torch.rand(n2d, 2, generator=g) - 0.5) * 6.0
+    am = torch.stack([torch.randint(0, n2d, (k,), generator=g), torch.randint(0, N + N // 10, (k,), generator=g)]).float()
+    am[:, k // 2: k // 2 + k // 20] = am[:, : k // 20]                                            # repeated pairs
+    am[1, k - k // 25:] = am[1, k - 2 * (k // 25): k - k // 25]                                    # same 3D point from other keypoints
+    return kc, kf, am, {"shape3d": N, "L": hc * wc, "w_c": wc, "scale": sc, "coarse_scale": 1.0 / 8}

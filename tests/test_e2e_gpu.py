@@ -175,14 +175,15 @@ def test_training_step_gradients(name):
     assert not torch.equal(e0["conf_matrix"], e1["conf_matrix"])
 
 
-def test_training_step_at_baseline_config5_size():
+@pytest.mark.parametrize("N", [7000, 15000])
+def test_training_step_at_baseline_config5_size(N):
     """BASELINE configs[4] shape on one GPU: B = 4 (train.yaml:185), 512x512 images, N = 7000 points (shape3d_train,
-    train.yaml:194): train()-mode forward on the HIP path + backward, one optimiser-style update; properties only
-    (the fixtures above pin the numbers at small sizes)."""
+    train.yaml:194) and N = 15000 (BASELINE.json configs[4]: "15k-point clouds" = max_num_kp3d): train()-mode forward on the HIP path +
+    backward, one optimiser-style update; properties only (the fixtures above pin the numbers at small sizes)."""
     from tests import hip_ops as ops
     from onepose_plus_plus_amd.config import default_config
     from onepose_plus_plus_amd.synthetic import make_state_dict, make_inputs
-    B, N, hw = 4, 7000, (512, 512)
+    B, hw = 4, (512, 512)
     cfg = default_config(thr=0.2)
     model = ops.make_model(cfg, make_state_dict(cfg, 0))
     model.train()
@@ -628,6 +629,7 @@ def test_object_prefix_is_bit_identical(hw, n):
 def _run_fine_variant(cfg, sd, data, precision, patch_max):
     from tests import hip_ops as ops
     m = ops.make_model(cfg, sd, precision).set_fine_patch_max_matches(patch_max)
+    m.fine_patch_pixels_per_match = 0                # force the path under test whatever the match count
     d = {k: v.cuda() for k, v in data.items()}
     with torch.no_grad():
         m(d)
