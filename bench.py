@@ -59,6 +59,7 @@ PREC_ID = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 1, "bf16x3": 2}
 GEMM_SYMBOLS = [
     (20, 1, "256, 128, 4, 2, true", "implicit-GEMM conv, 256x128 tile, 8 waves"),
     (22, 1, "128, 256, 2, 4, true", "implicit-GEMM conv, 128x256 tile, 8 waves"),
+    (24, 1, "128, 192, 4, 2, true", "implicit-GEMM conv, 128x192 tile, 8 waves: the 192-column body of the 196-channel layers (last 4 columns: conv_tail_kernel)"),
     (25, 1, "128, 128, 4, 2, true", "implicit-GEMM conv, 128x128 tile, 8 waves"),
     (26, 1, "64, 128, 2, 4, true", "implicit-GEMM conv, 64x128 tile, 8 waves"),
     (11, 1, "128, 128, 2, 2, true", "implicit-GEMM conv, 128x128 tile, 4 waves, prefetch depth 4"),
@@ -97,6 +98,8 @@ HBM_SYMBOLS = [
     (1001, "linattn_apply_pair_kernel", "linear-attention apply (Q read, message written)"),
     (1002, "conf_reg_kernel", "dual-softmax product over the N x L score matrix (read + written once)"),
     (1015, "splitk_epilogue_kernel", "K slices of a split convolution summed in slice order + bias / residual / activation"),
+    (1017, "conv_tail_kernel", "columns 192 .. 223 of the 196-channel convolutions: 4 fp32 FMA chains per pixel on the vector ALU + the zero padding "
+                               "channels (input read once, one 128-byte line per pixel written)"),
     (1016, "linattn_reduce_pair_kernel", "fixed-order sum of the attention gather's chunk partials (partials read, KV / Ksum written)"),
 ]
 # launch shapes that are ONE kernel symbol in a rocprofv3 trace: (symbol of the entry that absorbs, symbol absorbed).  The K slices of the
@@ -127,8 +130,10 @@ def parse_args():
     ap.add_argument("--no-legs", action="store_true", help="skip the other-arithmetic and fine-stage legs")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "fp32", "fp16x2", "fp16x2_all"],
                     help="GEMM arithmetic (default: the module default bf16x3 / OPP_GEMM_PRECISION)")
-    ap.add_argument("--tile-policy", default="latency", choices=["latency", "throughput"],
-                    help="automatic GEMM / conv tile choice for the headline (opp_config.tile_policy); the other one is reported as a leg")
+    ap.add_argument("--tile-policy", default="auto", choices=["auto", "latency", "throughput"],
+                    help="automatic GEMM / conv tile choice of the timed region (opp_config.tile_policy); auto = what serving.MatcherPool does: "
+                         "throughput (least CU time per launch) with several forwards in flight, latency (every launch sized to fill the chip) "
+                         "with one; the other one is reported as a leg.  The per-kernel roofline pass is single-stream and always uses the latency tiles.")
     ap.add_argument("--fpn-overlap", default="auto", choices=["auto", "on", "off"],
                     help="FPN fine branch on a side HIP stream (opp_config.fpn_overlap); auto = on for one forward in flight, off for "
                          "several (the other forwards are the overlap; extra streams only crowd the hardware queues)")
@@ -296,13 +301,16 @@ def run(args):
     else:
         model.load_state_dict(sd, strict=True)
     n_streams = max(1, args.streams)
-    # scheduling switches (bit-identical results either way).  Tiles: the headline and its roofline use the per-launch-latency
-    # tiles, whose kernels fill the chip on their own, so a symbol's stand-alone duration is a meaningful roofline figure; the
-    # least-CU-time tiles serving.MatcherPool uses with several forwards in flight (other forwards' kernels take the CUs a launch
-    # leaves idle; 491 -> 512 images/s at 3 streams, tools/ab_queues.sh) are reported as `throughput_tiles_leg`.  Side stream of
-    # the FPN fine branch: on for one forward in flight, off for several (the other forwards are the overlap; more streams only
-    # crowd the hardware queues: -0.7 % with the latency tiles, -3 % with the throughput tiles).
+    # scheduling switches (bit-identical results either way).  Tiles follow the number of forwards in flight, as serving.MatcherPool
+    # sets them: with several forwards in flight other forwards' kernels take the CUs a launch leaves idle, so the tiles with the
+    # least CU time per launch win (`throughput`: +4 % images/s at 3 streams in rounds 3 / 4, where it was a leg); with one forward
+    # in flight -- and in the per-kernel roofline pass, which is single-stream -- every launch is sized to fill the chip on its own
+    # (`latency`), so a symbol's stand-alone duration is a meaningful roofline figure.  The other policy is reported as a leg.  Side
+    # stream of the FPN fine branch: on for one forward in flight, off for several (the other forwards are the overlap; more streams
+    # only crowd the hardware queues: -0.7 % with the latency tiles, -3 % with the throughput tiles).
     policy = args.tile_policy
+    if policy == "auto":
+        policy = "throughput" if n_streams > 1 else "latency"
     overlap = (n_streams == 1) if args.fpn_overlap == "auto" else args.fpn_overlap == "on"
     if args.fpn_overlap == "auto" and "OPP_FPN_OVERLAP" in os.environ:
         overlap = os.environ["OPP_FPN_OVERLAP"] != "0"
@@ -396,12 +404,15 @@ def run(args):
         # a kernel's own duration: one forward in flight AND the FPN fine branch on the same stream (with opp_config.fpn_overlap
         # the coarse-level kernels share the CUs with the fine-branch convolutions and every launch of both stretches)
         for m in models:
-            m.set_fpn_overlap(False).to(dev)
+            m.set_fpn_overlap(False).set_tile_policy("latency").to(dev)
         step(0, 0)
         torch.cuda.synchronize(dev)
         roof = roofline_leg(lib, _lib, torch, dev, step, precision, min(args.steps * ips, 20))
+        if roof is not None:
+            roof["tile_policy"] = ("latency (single-stream pass: every launch sized to fill the chip on its own; the timed region ran the "
+                                   "%s tiles with %d forward(s) in flight)" % (policy, n_streams))
         for m in models:
-            m.set_fpn_overlap(overlap).to(dev)
+            m.set_fpn_overlap(overlap).set_tile_policy(policy).to(dev)
         for k in range(n_streams):
             step(0, k)
         torch.cuda.synchronize(dev)

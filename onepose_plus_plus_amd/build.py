@@ -22,7 +22,7 @@ OBJ = os.path.join(HERE, "csrc", "_build")
 LIB = os.path.join(HERE, "libopp_hip.so")
 SOURCES = ["gemm_mfma.hip", "gemm_ss.hip", "enc_chain.hip", "enc_layer64.hip", "stem_direct.hip", "attention.hip", "backbone.hip", "kpt.hip",
            "coarse_match.hip", "fine.hip", "pnp.hip", "ingest.hip", "profile.hip", "bn_train.hip", "bankbuild.hip", "loss.hip", "linear_bwd.hip",
-           "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "version.hip", "api.hip"]
+           "linattn_train.hip", "conv_bwd.hip", "train_misc.hip", "conv_tail.hip", "version.hip", "api.hip"]
 HEADERS = ["opp_common.h", "opp_internal.h", "enc_frag.h", "pnp_math.h", os.path.join("..", "..", "include", "opp_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source extras.  The two files whose kernels split fp32 values into bf16 triples beside MFMAs: the SLP vectorizer pairs the

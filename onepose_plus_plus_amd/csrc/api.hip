@@ -56,6 +56,12 @@ struct ConvDesc {  // one packed convolution
   // affine parameters of the BatchNorm that follows this convolution
   float* w_train = nullptr;
   float* h2s_train = nullptr;
+  // bf16x3, cout = 32 n + (1..4) with n >= 2 (the 196-channel layers): the last columns as fp32 FMA chains (conv_tail.hip) beside a body of
+  // 32 n columns on the MFMA kernel; [taps][cin_pad][4] fp32, BatchNorm scale folded (w_tail) / raw (w_tail_train)
+  float* w_tail = nullptr;
+  float* w_tail_train = nullptr;
+  int tail_cols() const { return (cout % 32 >= 1 && cout % 32 <= 4 && cout >= 64) ? cout % 32 : 0; }
+  int body_cols() const { return cout / 32 * 32; }
   const float* gamma = nullptr;
   const float* beta = nullptr;
   int bn_slot = -1;       // index of that BatchNorm among the backbone's BatchNorm layers (state-dict order)
@@ -348,6 +354,7 @@ size_t plan_pack(opp_ctx* c, void* base) {
     d->h2s = h2 ? a.f(2) : nullptr;
     d->w = wf(d->w_floats());
     d->bias = d->bn_idx >= 0 ? a.f(d->cout_pad()) : nullptr;
+    d->w_tail = (prec == OPP_PREC_BF16X3 && d->tail_cols()) ? a.f(opp_conv_tail_weight_floats(d->cin_pad(), d->ks)) : nullptr;
   }
   if (c->cfg.kpt_enc_enable) {
     const int ch[5] = {3, c->cfg.kpt_enc_dims[0], c->cfg.kpt_enc_dims[1], c->cfg.kpt_enc_dims[2], c->cfg.coarse_d_model};
@@ -435,6 +442,7 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
     OPP_TRY(place(d->w, d->w_floats(), d->h2s, [&](float* dst) {
       return opp_pack_conv(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), dst, s);
     }));
+    if (d->w_tail) OPP_TRY(opp_pack_conv_tail(w[d->w_idx], scale, d->cout, d->cin, d->ks, d->body_cols(), d->cin_pad(), d->w_tail, s));
   }
   const bool with_tr = c->pack_scope == 0;
   if (c->cfg.kpt_enc_enable && with_tr) {
@@ -516,6 +524,7 @@ size_t plan_pack_train(opp_ctx* c, void* base) {
     if (d->bn_idx < 0) continue;      // no BatchNorm behind it: the eval packing is already the raw weight
     d->w_train = a.f(split_floats(d->w_floats(), prec));
     d->h2s_train = h2 ? a.f(2) : nullptr;
+    d->w_tail_train = (prec == OPP_PREC_BF16X3 && d->tail_cols()) ? a.f(opp_conv_tail_weight_floats(d->cin_pad(), d->ks)) : nullptr;
   }
   return opp_align(a.off);
 }
@@ -550,6 +559,7 @@ extern "C" int opp_pack_train_weights(opp_ctx* c, const float* const* w, int n, 
     OPP_TRY(place(d->w_train, d->w_floats(), d->h2s_train, [&](float* dst) {
       return opp_pack_conv(w[d->w_idx], nullptr, d->cout, d->cin, d->ks, d->cout_pad(), d->cin_pad(), dst, s);
     }));
+    if (d->w_tail_train) OPP_TRY(opp_pack_conv_tail(w[d->w_idx], nullptr, d->cout, d->cin, d->ks, d->body_cols(), d->cin_pad(), d->w_tail_train, s));
     d->gamma = w[d->bn_idx];          // caller-owned: must outlive the training forwards
     d->beta = w[d->bn_idx + 1];
   }
@@ -633,6 +643,18 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   }
   g.act = act;
   g.alg_flops = 2.0 * (double)g.M * (double)d.cout * (double)(d.ks * d.ks * d.cin);
+  // 196-channel layers (bf16x3): 192 columns on the MFMA kernel -- no padded sub-tile -- and the last 4 (+ the zero padding channels of
+  // the 224-channel row) on the vector ALU.  Shape-only decision: every tile policy, batch size and the match-driven patches take it.
+  static const bool tail_on = !(getenv("OPP_CONV_TAIL") && getenv("OPP_CONV_TAIL")[0] == '0');   // A/B switch of the tools
+  const float* wt = raw ? d.w_tail_train : d.w_tail;
+  if (tail_on && h2 == OPP_PREC_BF16X3 && wt != nullptr && tile_cfg < 0) {
+    OppGemm body = g;
+    body.N = d.body_cols();
+    body.n_store = d.body_cols();
+    body.alg_flops = 2.0 * (double)g.M * (double)d.body_cols() * (double)(d.ks * d.ks * d.cin);
+    OPP_TRY(opp_gemm_launch_cfg(body, tile_cfg, s));
+    return opp_conv_tail(g, wt, d.body_cols(), d.tail_cols(), s);
+  }
   return opp_gemm_launch_cfg(g, tile_cfg, s);
 }
 

@@ -1044,12 +1044,10 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // split-operand variants are instantiated for the tiles their policies can pick only (depth 2: deeper prefetch measured
   // no better with the shorter MFMA phase; the 4-wave 128-column tiles are fp32 tiles)
   // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
-#ifdef OPP_TUNING
-  constexpr bool kTuning192 = BM == 128 && BN == 192 && NT == 512 && PREC == OPP_PREC_BF16X3;   // tile config 140 of the tuning library
-#else
-  constexpr bool kTuning192 = false;
-#endif
-  constexpr bool ok = PREC == OPP_PREC_FP32 ||
+  // 128 x 192 on 8 waves (32 x 96 per wave, 219 registers, 133 KB of LDS): the 192-column body of the 196-channel layers, whose last 4
+  // columns come from conv_tail.hip (round 5; config 24)
+  constexpr bool kTuning192 = BM == 128 && BN == 192 && NT == 512 && PREC == OPP_PREC_BF16X3;
+  constexpr bool ok = (PREC == OPP_PREC_FP32 && BN != 192) ||
                       (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64) || (PREC == OPP_PREC_FP16X2 && BM == 128 && BN == 128)) &&
                        (BN == 128 || BN == 64 || BN == 256 || kTuning192) &&
                        (PREC != OPP_PREC_BF16X3 || (BN * 12) % NT == 0 || kTuning192) && (PREC != OPP_PREC_BF16X3 || BM * BN / NT <= 64 || kTuning192));
@@ -1137,7 +1135,7 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
     case 193: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
     // 192-column tile for the 196-channel layers as 192 + a 4-column tail: 32 x 96 per wave, 219 registers, no scratch, 133 KB of LDS
     // (the 256 x 192 tile, 64 x 96 per wave, spills 248 bytes: not built).  NOT measured yet -- compiled for the next conv_bench runs.
-    case 140: return h3 ? launch_prec<128, 192, 4, 2, 2, OPP_PREC_BF16X3>(g, stream, 0) : OPP_ERR_INVALID;
+    case 140: return h3 ? launch_prec<128, 192, 4, 2, 2, OPP_PREC_BF16X3>(g, stream, 0) : OPP_ERR_INVALID;   // (= product config 24)
     case 101: return g.conv ? launch_ablate<1>(g, stream) : OPP_ERR_INVALID;
     case 102: return g.conv ? launch_ablate<2>(g, stream) : OPP_ERR_INVALID;
     case 103: return g.conv ? launch_ablate<3>(g, stream) : OPP_ERR_INVALID;
@@ -1268,7 +1266,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       // wpc = workgroups of this tile that share a CU (by LDS); co-resident workgroups share the matrix pipes, so a
       // chunk then costs wpc x the stand-alone time.
       struct Cand { int cfg, bm, bn, wpc, chunk, fixed; };
-      static const Cand cands[] = {{22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
+      // (24: 128 x 192, for outputs that are whole 192-column tiles -- the body of a 196-channel layer: measured 228 us against 272 on the
+      // 128 x 256 tile at 256 x 256 pixels, profiles/r05_conv_bench_192_columns.txt)
+      static const Cand cands[] = {{24, 128, 192, 1, 4000, 16000}, {22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
                                    {25, 128, 128, 1, 2600, 13000}, {26, 64, 128, 2, 1400, 11000},
                                    {2, 64, 64, 3, 1000, 9000}};
       const long long nk = g.K / 32, cus = 256;
@@ -1283,6 +1283,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
         if (skip_env && (c.cfg == 20 || c.cfg == 22)) continue;
 #endif
         if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
+        if (c.bn == 192 && g.n_store % 192 != 0) continue;
         const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
         const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
         long long est = full * (nk * c.chunk * c.wpc + c.fixed);
@@ -1327,6 +1328,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 11: rc = launch_cfg<128, 128, 2, 2, 4>(g, stream); break;
     case 20: rc = launch_cfg<256, 128, 4, 2>(g, stream); break;     // 8 waves: two per SIMD
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
+    case 24: rc = launch_cfg<128, 192, 4, 2>(g, stream); break;     // 8 waves, 32x96 per wave: 192-column bodies of the 196-channel layers
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)

@@ -21,6 +21,7 @@ enum {
   OPP_PROF_SCORE_SWEEP2 = 1011,
   OPP_PROF_CONV_WGRAD = 1013,      // conv_wgrad_kernel: weight gradient of a convolution / Linear (work = FLOPs)
   OPP_PROF_CONV_SPLITK = 1014,     // opp_gemm_kernel<128,128,conv> over 4 K slices: the 3x3 convolutions of the 1/8-resolution stage (FLOPs)
+  OPP_PROF_CONV_TAIL = 1017,       // conv_tail_kernel: columns 192 .. 223 of the 196-channel convolutions on the vector ALU (work = bytes)
   OPP_PROF_LINATTN_REDUCE = 1016,  // linattn_reduce_pair_kernel: fixed-order sum of the KV chunk partials (work = bytes)
   OPP_PROF_SPLITK_EPILOGUE = 1015, // splitk_epilogue_kernel: slices summed + bias / residual / activation (work = bytes)
   OPP_PROF_SCORE_SS = 1012,        // gemm_ss_kernel<STATS_STORE>: score GEMM on pre-split operands, statistics + score matrix written (FLOPs)    // gemm_ss_kernel<CONF>: score tiles recomputed -> confidence matrix written once (work = FLOPs)
@@ -160,6 +161,11 @@ int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const 
 // stem_direct.hip -- 7x7 / stride 2 stem + bias + ReLU without the im2col matrix (bf16x3, 128 output channels)
 bool opp_stem_direct_ok(int cout, int prec);
 int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream);
+// conv_tail.hip -- the last (cout mod 32 <= 4) output columns of a convolution as fp32 FMA chains (the 196-channel layers: 192 columns on the
+// MFMA kernel + 4 here instead of 224 / 256 padded MFMA columns)
+size_t opp_conv_tail_weight_floats(int cin_pad, int ks);
+int opp_pack_conv_tail(const float* w, const float* scale, int cout, int cin, int ks, int n0, int cin_pad, float* wt, hipStream_t stream);
+int opp_conv_tail(const OppGemm& g, const float* wt, int n0, int ncols, hipStream_t stream);
 // backbone.hip
 int opp_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int c,
                 int c_pad, float* scale, float* shift, hipStream_t stream);
