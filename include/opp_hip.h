@@ -112,6 +112,11 @@ int opp_set_query_mask(opp_ctx* ctx, const float* mask);
  * batch element 0 (NULL = each cloud uses its own extent, the B = 1 behaviour).  Applies to opp_encode_points,
  * opp_coarse_tokens and opp_forward_coarse. */
 int opp_set_keypoint_extent_ref(opp_ctx* ctx, const float* kpts0, int n0);
+/* bf16x3 arithmetic, opt-in (default off; OPP_CONV_TAIL=1 turns it on for every context): the convolutions with 196 output channels
+ * (backbone/resnet.py:88-124, block_dims[1]) as a 192-column body on the MFMA kernel (tile 128 x 192, no padded column sub-tile) + their
+ * last 4 columns as fp32 FMA chains on the vector ALU (csrc/conv_tail.hip).  Same parity bar; measured slower with one forward in flight
+ * and equal with three, hence not the default. */
+int opp_set_conv_tail(opp_ctx* ctx, int on);
 /* fp16x2 range guard (gemm_precision 1 / 2 only; a no-op otherwise): `flag` is a device int that every stage
  * enqueued through this ctx ORs with 1 when an fp16x2 GEMM produced a non-finite value, i.e. an activation left the
  * fp16 range (|x| >~ 1.3e5) -- or the input itself was not finite.  The caller zeroes it, reads it after the

@@ -52,6 +52,7 @@ SIGNATURES = {
     "opp_destroy": (None, [c_void_p]),
     "opp_set_status_flag": (c_int, [c_void_p, c_void_p]),
     "opp_set_query_mask": (c_int, [c_void_p, c_void_p]),
+    "opp_set_conv_tail": (c_int, [c_void_p, c_int]),
     "opp_set_keypoint_extent_ref": (c_int, [c_void_p, c_void_p, c_int]),
     "opp_num_weights": (c_int, [c_void_p]),
     "opp_weight_name": (c_char_p, [c_void_p, c_int]),

@@ -108,6 +108,9 @@ struct opp_ctx {
   int kpt_extent_n = 0;
   const float* obj_prefix = nullptr;      // opp_set_object_prefix: result of opp_object_prefix for the CURRENT object, or null
   int obj_prefix_n = 0;
+  // opp_set_conv_tail: 196-channel layers as a 192-column MFMA body + a 4-column fp32 tail (conv_tail.hip).  Measured slower for one forward
+  // in flight and equal with three, so off unless asked for (OPP_CONV_TAIL=1 turns it on for every context)
+  bool conv_tail = getenv("OPP_CONV_TAIL") && getenv("OPP_CONV_TAIL")[0] == '1';
   float* fine_x1 = nullptr;               // opp_set_fine_patch_buffers: caller-owned x1 / x2_out of the CURRENT image (match-driven fine branch)
   float* fine_x2o = nullptr;
   float* scratch_scale = nullptr;  // [256] BN scale temp inside the blob
@@ -132,16 +135,20 @@ namespace {
 // built below picks it up)
 thread_local int* t_status_flag = nullptr;
 thread_local int t_tile_policy = OPP_TILES_LATENCY;   // opp_config.tile_policy of that ctx
+thread_local bool t_conv_tail = false;                // opp_set_conv_tail of that ctx
 struct FlagScope {
   int* prev;
   int prev_policy;
-  explicit FlagScope(const opp_ctx* c) : prev(t_status_flag), prev_policy(t_tile_policy) {
+  bool prev_tail;
+  explicit FlagScope(const opp_ctx* c) : prev(t_status_flag), prev_policy(t_tile_policy), prev_tail(t_conv_tail) {
     t_status_flag = c ? c->status_flag : nullptr;
     t_tile_policy = c ? c->cfg.tile_policy : OPP_TILES_LATENCY;
+    t_conv_tail = c ? c->conv_tail : false;
   }
   ~FlagScope() {
     t_status_flag = prev;
     t_tile_policy = prev_policy;
+    t_conv_tail = prev_tail;
   }
 };
 
@@ -284,6 +291,11 @@ extern "C" void opp_destroy(opp_ctx* ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
+}
+extern "C" int opp_set_conv_tail(opp_ctx* ctx, int on) {
+  OPP_CHECK_ARG(ctx && (on == 0 || on == 1), "set_conv_tail: on must be 0 or 1");
+  ctx->conv_tail = on != 0;
+  return OPP_OK;
 }
 extern "C" int opp_set_query_mask(opp_ctx* ctx, const float* mask) {
   OPP_CHECK_ARG(ctx, "set_query_mask: null ctx");
@@ -645,9 +657,8 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.alg_flops = 2.0 * (double)g.M * (double)d.cout * (double)(d.ks * d.ks * d.cin);
   // 196-channel layers (bf16x3): 192 columns on the MFMA kernel -- no padded sub-tile -- and the last 4 (+ the zero padding channels of
   // the 224-channel row) on the vector ALU.  Shape-only decision: every tile policy, batch size and the match-driven patches take it.
-  static const bool tail_on = !(getenv("OPP_CONV_TAIL") && getenv("OPP_CONV_TAIL")[0] == '0');   // A/B switch of the tools
   const float* wt = raw ? d.w_tail_train : d.w_tail;
-  if (tail_on && h2 == OPP_PREC_BF16X3 && wt != nullptr && tile_cfg < 0) {
+  if (t_conv_tail && h2 == OPP_PREC_BF16X3 && wt != nullptr && tile_cfg < 0) {
     OppGemm body = g;
     body.N = d.body_cols();
     body.n_store = d.body_cols();
@@ -1020,12 +1031,13 @@ int backbone_tape_impl(opp_ctx* c, const float* image, int B, int H, int W, floa
 // ---- backward of ONE convolution over NHWC tensors (channel counts padded to 32) --------------------------------------------
 struct ConvBwdWs {
   float *wt_tmp = nullptr, *wt_pack = nullptr, *wt_split = nullptr;   // flipped / transposed weight, packed, pre-split
+  float* wt_tail = nullptr;                                            // its last <= 4 output columns for conv_tail.hip (196-channel inputs)
   float* zbuf = nullptr;                                               // zero-inserted dY of a stride-2 convolution
   void* geo = nullptr;
   void* wg = nullptr;
   size_t wg_bytes = 0;
 };
-struct ConvBwdNeed { size_t wt_tmp = 0, wt_pack = 0, wt_split = 0, zbuf = 0, geo = 0, wg = 0; };
+struct ConvBwdNeed { size_t wt_tmp = 0, wt_pack = 0, wt_split = 0, wt_tail = 0, zbuf = 0, geo = 0, wg = 0; };
 
 void conv_bwd_need(ConvBwdNeed& n, int B, int Hin, int Win, int cin, int cout, int ks, int stride, bool need_dx, bool need_dw, int prec) {
   const int Ho = (Hin + 2 * (ks / 2) - ks) / stride + 1, Wo = (Win + 2 * (ks / 2) - ks) / stride + 1;
@@ -1035,6 +1047,7 @@ void conv_bwd_need(ConvBwdNeed& n, int B, int Hin, int Win, int cin, int cout, i
     const size_t pk = (size_t)pad32(cin) * opp_conv_k(cout, ks);
     mx(n.wt_pack, pk);
     mx(n.wt_split, split_floats(pk, prec));
+    mx(n.wt_tail, opp_conv_tail_weight_floats(pad32(cout), ks));
     if (stride == 2) mx(n.zbuf, (size_t)B * Hin * Win * pad32(cout));
   }
   if (need_dw) {
@@ -1046,6 +1059,7 @@ void conv_bwd_alloc(Arena& a, const ConvBwdNeed& n, ConvBwdWs& w) {
   w.wt_tmp = a.f(n.wt_tmp);
   w.wt_pack = a.f(n.wt_pack);
   w.wt_split = a.f(n.wt_split);
+  w.wt_tail = a.f(n.wt_tail);
   w.zbuf = a.f(n.zbuf);
   w.geo = a.raw(n.geo);
   w.wg = a.raw(n.wg);
@@ -1113,7 +1127,20 @@ int conv_backward(const float* x, int B, int Hin, int Win, int cin, const float*
       g.ldr = cin_pad;
     }
     g.alg_flops = 2.0 * (double)B * Ho * Wo * (double)cout * (double)(ks * ks * cin);
-    OPP_TRY(opp_gemm_launch(g, s));
+    // an input of 196 channels: its gradient is a 196-column output -> 192 columns on the MFMA kernel + a 4-column tail, as in the forward
+    const int tail = (cin % 32 >= 1 && cin % 32 <= 4 && cin >= 64) ? cin % 32 : 0;
+    if (t_conv_tail && tail && prec == OPP_PREC_BF16X3 && ws.wt_tail != nullptr) {
+      const int n0 = cin / 32 * 32;
+      OPP_TRY(opp_pack_conv_tail(ws.wt_tmp, nullptr, cin, cout, ks, n0, cout_pad, ws.wt_tail, s));    // wt_tmp = [cin][cout][ks][ks], flipped
+      OppGemm body = g;
+      body.N = n0;
+      body.n_store = n0;
+      body.alg_flops = g.alg_flops * (double)n0 / (double)cin;
+      OPP_TRY(opp_gemm_launch(body, s));
+      OPP_TRY(opp_conv_tail(g, ws.wt_tail, n0, tail, s));
+    } else {
+      OPP_TRY(opp_gemm_launch(g, s));
+    }
   }
   return OPP_OK;
 }

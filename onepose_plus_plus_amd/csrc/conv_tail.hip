@@ -7,22 +7,27 @@
 // pixel, 2 % of the layer's work, exact fp32 (not narrower than the six-product bf16 arithmetic of the body) -- and exact zeros in the 28
 // padding channels.  It runs for every tile policy and batch size, so results never depend on the tile shape of the body.
 //
-// Structure: a workgroup (4 waves) owns an 8 x 8 tile of output pixels of one image (or one whole patch of the match-driven fine
-// branch: VALID convolution, 7 x 7 / 5 x 5 outputs); lane = pixel, wave = 8 of the 32 channels of the current channel group.  Per
-// group the input footprint ((8 - 1) * stride + ks)^2 pixels x 32 channels is staged once in LDS (coalesced 16-byte loads, zeros for
-// the padding halo), every lane then walks taps x 8 channels with two ds_read_b128 per tap; the four weights of a (tap, channel) are
-// one scalar load (wave-uniform).  The four channel slices are summed through LDS in slice order, then bias (folded BatchNorm),
-// residual (same tensor or bilinear x2, align_corners=True, the arithmetic of the GEMM epilogue), activation.  Deterministic.
+// Structure: a workgroup (4 waves) owns a 16-wide tile of output pixels of one image (8 rows x 16 columns; or one
+// whole patch of the match-driven fine branch: VALID convolution, 7 x 7 / 5 x 5 outputs); a lane owns PPL = 2 vertically adjacent
+// pixels, a wave 8 of the 32 channels of the current channel group.  Per group the input footprint x 32 channels AND the group's
+// weights (taps x 32 channels x 4 columns) are staged once in LDS (coalesced 16-byte loads, zeros for the padding halo; the next
+// group's loads fly under the arithmetic).  Per tap column kx a lane reads the 8 channels of its PPL + ks - 1 input rows once and
+// reuses them for the ks taps above each other; the four weights of a (tap, channel) are one broadcast ds_read_b128 shared by the PPL
+// pixels -- 0.19 LDS reads per packed FMA, so the vector ALU, not the LDS pipe, is the limit.  (The first version fetched the weights
+// with scalar loads: 32 KB of weights cycling through the 16 KB scalar cache missed on every tap and, since scalar loads return out of
+// order, could not be pipelined -- ~1000 cycles per tap, 250 us per forward; profiles/r05_conv_tail_v1_trace.txt.)  The four channel
+// slices are summed through LDS in slice order, then bias (folded BatchNorm), residual (same tensor or bilinear x2, align_corners=True,
+// the arithmetic of the GEMM epilogue), activation.  Deterministic.
 #include "opp_internal.h"
 
 namespace {
 
-constexpr int TP = 8;                 // output tile edge
+constexpr int TW = 16;                // output tile width
 constexpr int LS = 36;                // LDS floats per staged pixel (32 channels + 4 pad: ds_read_b128 lane groups spread over the banks)
 
 struct TailArgs {
   const float* x;                     // NHWC [Bn][Hin][Win][cin_pad]
-  const float* wt;                    // [taps][cin_pad][4]: the four tail columns of a (tap, input channel) contiguous
+  const float* wt;                    // [cin_pad / 32][taps][32][4]: per channel group, the four tail columns of a (tap, channel) contiguous
   const float* bias;                  // [cout_pad] or null
   const float* R;                     // residual or null
   float* y;                           // [Bn * Hout * Wout][ldc]
@@ -31,64 +36,127 @@ struct TailArgs {
   float res_sy, res_sx;
 };
 
-__global__ __launch_bounds__(256) void conv_tail_kernel(const TailArgs a) {
+template <int KS, int STRIDE>
+__global__ __launch_bounds__(256, 3) void conv_tail_kernel(const TailArgs a) {      // <= 168 registers: three workgroups (12 waves) per CU hide the LDS latency
   extern __shared__ __attribute__((aligned(16))) float sh[];
+  constexpr int PPL = 2;                                          // output pixels per lane (vertically adjacent): 8 x 16 tiles -> enough workgroups at 128 x 128 pixels
+  constexpr int TH = 4 * PPL;                                     // output tile height
+  constexpr int IWX = (TW - 1) * STRIDE + KS, IWY = (TH - 1) * STRIDE + KS;   // staged footprint
+  constexpr int NITEM = IWX * IWY * 8;                            // float4 pieces of one staged channel group
+  constexpr int NL = (NITEM + 255) / 256;                         // ... per thread
+  constexpr bool PREFETCH = NL <= 8;                              // the stride-2 footprints (18 pieces per thread) are staged without the register stage
+  constexpr int TAPS = KS * KS;
+  constexpr int NR = (PPL - 1) * STRIDE + KS;                     // input rows a lane touches
+  constexpr int WOFF = IWX * IWY * LS;                            // the group's weights behind the staged pixels
   const int tid = threadIdx.x, lane = tid & 63;
   const int part = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = channel slice [8 part, 8 part + 8) of the group
-  const int ntx = (a.Wout + TP - 1) / TP;
-  const int ty0 = ((int)blockIdx.x / ntx) * TP, tx0 = ((int)blockIdx.x % ntx) * TP;
+  const int ntx = (a.Wout + TW - 1) / TW;
+  const int ty0 = ((int)blockIdx.x / ntx) * TH, tx0 = ((int)blockIdx.x % ntx) * TW;
   const int b = blockIdx.y;
-  const int IW = (TP - 1) * a.stride + a.ks;                       // staged footprint edge
-  const int iy0 = ty0 * a.stride - a.pad, ix0 = tx0 * a.stride - a.pad;
-  const int ly = (lane >> 3) * a.stride, lx = (lane & 7) * a.stride;
+  const int iy0 = ty0 * STRIDE - a.pad, ix0 = tx0 * STRIDE - a.pad;
+  const int lpx = lane & 15, lpy = (lane >> 4) * PPL;             // this lane's pixels: (ty0 + lpy + j, tx0 + lpx), j < PPL
   const float* xb = a.x + (size_t)b * a.Hin * a.Win * a.cin_pad;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int taps = a.ks * a.ks;
+  // this thread's pieces of a staged group (NL float4 of the footprint, <= 2 float4 of the weights), loaded one group ahead
+  float4 pre[NL];
+  float4 wpre0 = make_float4(0.f, 0.f, 0.f, 0.f), wpre1 = wpre0;
+  auto fetch = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e = tid + i * 256;
+      const int p = e >> 3, q = e & 7;
+      const int py = p / IWX, px = p - py * IWX;
+      const int iy = iy0 + py, ix = ix0 + px;
+      pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);                    // padding halo / past the footprint
+      if (e < NITEM && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+        pre[i] = *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.Win + ix) * a.cin_pad + q * 4 + g0);
+    }
+    const float4* wg = reinterpret_cast<const float4*>(a.wt) + (size_t)(g0 >> 5) * (TAPS * 32);
+    if (tid < TAPS * 32) wpre0 = wg[tid];
+    if (TAPS * 32 > 256 && tid + 256 < TAPS * 32) wpre1 = wg[tid + 256];
+  };
+  float acc[PPL][4];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+  if (PREFETCH) fetch(0);
   for (int g0 = 0; g0 < a.cin_pad; g0 += 32) {
     __syncthreads();                                               // the previous group's tile is consumed
-    for (int e = tid; e < IW * IW * 8; e += 256) {                 // 8 float4 per staged pixel
-      const int p = e >> 3, q = e & 7;
-      const int py = p / IW, px = p - py * IW;
-      const int iy = iy0 + py, ix = ix0 + px;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
-        v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.Win + ix) * a.cin_pad + g0 + q * 4);
-      *reinterpret_cast<float4*>(sh + p * LS + q * 4) = v;
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int e = tid + i * 256;
+        if (e < NITEM) *reinterpret_cast<float4*>(sh + (e >> 3) * LS + (e & 7) * 4) = pre[i];
+      }
+      if (tid < TAPS * 32) *reinterpret_cast<float4*>(sh + WOFF + tid * 4) = wpre0;
+      if (TAPS * 32 > 256 && tid + 256 < TAPS * 32) *reinterpret_cast<float4*>(sh + WOFF + (tid + 256) * 4) = wpre1;
+    } else {
+      // large (stride-2) footprints: global -> LDS four pieces at a time, no register stage
+      const float4* wg = reinterpret_cast<const float4*>(a.wt) + (size_t)(g0 >> 5) * (TAPS * 32);
+      for (int e = tid; e < TAPS * 32; e += 256) *reinterpret_cast<float4*>(sh + WOFF + e * 4) = wg[e];
+#pragma unroll 4
+      for (int e = tid; e < NITEM; e += 256) {
+        const int p = e >> 3, q = e & 7;
+        const int py = p / IWX, px = p - py * IWX;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+          v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * a.Win + ix) * a.cin_pad + q * 4 + g0);
+        *reinterpret_cast<float4*>(sh + p * LS + q * 4) = v;
+      }
     }
     __syncthreads();
-    const float4* w4 = reinterpret_cast<const float4*>(a.wt) + g0 + part * 8;
-    for (int t = 0; t < taps; ++t) {
-      const int ky = t / a.ks, kx = t - ky * a.ks;
-      const float* src = sh + ((ly + ky) * IW + lx + kx) * LS + part * 8;
-      const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
-      const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      const float4* wr = w4 + (size_t)t * a.cin_pad;
+    if (PREFETCH && g0 + 32 < a.cin_pad) fetch(g0 + 32);           // the next group's loads fly under this group's arithmetic
+    const float* wsh = sh + WOFF + part * 32;                      // [tap][32 channels][4]: this wave's 8 channels
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 w = wr[i];                                    // wave-uniform address: a scalar load
-        acc[0] = fmaf(xs[i], w.x, acc[0]);
-        acc[1] = fmaf(xs[i], w.y, acc[1]);
-        acc[2] = fmaf(xs[i], w.z, acc[2]);
-        acc[3] = fmaf(xs[i], w.w, acc[3]);
+    for (int kx = 0; kx < KS; ++kx) {
+      float xr[NR][8];                                             // the 8 channels of the NR input rows this lane's pixels see in column kx
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const float* src = sh + ((lpy * STRIDE + r) * IWX + lpx * STRIDE + kx) * LS + part * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+        xr[r][0] = x0.x; xr[r][1] = x0.y; xr[r][2] = x0.z; xr[r][3] = x0.w;
+        xr[r][4] = x1.x; xr[r][5] = x1.y; xr[r][6] = x1.z; xr[r][7] = x1.w;
+      }
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const float* wt_ = wsh + (ky * KS + kx) * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float4 w = *reinterpret_cast<const float4*>(wt_ + i * 4);   // same address in every lane: an LDS broadcast
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) {
+            const float xv = xr[j * STRIDE + ky][i];
+            acc[j][0] = fmaf(xv, w.x, acc[j][0]);
+            acc[j][1] = fmaf(xv, w.y, acc[j][1]);
+            acc[j][2] = fmaf(xv, w.z, acc[j][2]);
+            acc[j][3] = fmaf(xv, w.w, acc[j][3]);
+          }
+        }
       }
     }
   }
   __syncthreads();
-  float4* red = reinterpret_cast<float4*>(sh);                     // [4 slices][64 pixels]
-  red[part * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  float4* red = reinterpret_cast<float4*>(sh);                     // [4 slices][TH * TW pixels]
+  constexpr int NPIX = TH * TW;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) red[part * NPIX + (lpy + j) * TW + lpx] = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   __syncthreads();
-  const int oy = ty0 + (lane >> 3), ox = tx0 + (lane & 7);
+  // thread = output pixel of the tile (stride 2: the upper half of the workgroup writes the padding channels of the same pixels)
+  const int pix = tid % NPIX, role = tid / NPIX;                   // NPIX = 256 (one role) or 128 (role 0: values + half the zeros, 1: the rest)
+  const int oy = ty0 + pix / TW, ox = tx0 + pix % TW;
   if (oy >= a.Hout || ox >= a.Wout) return;
   const size_t row = ((size_t)b * a.Hout + oy) * a.Wout + ox;
   float* out = a.y + row * a.ldc + a.n0;
-  if (part != 0) {                                                 // the padding channels of the 32-column line: exact zeros
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(out + 8 * part - 4) = z;
-    *reinterpret_cast<float4*>(out + 8 * part) = z;
-    if (part == 3) *reinterpret_cast<float4*>(out + 28) = z;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (role != 0) {                                                 // the padding channels of the 32-column line: exact zeros
+#pragma unroll
+    for (int q = 4; q < 8; ++q) *reinterpret_cast<float4*>(out + 4 * q) = z;
     return;
   }
-  const float4 s0 = red[lane], s1 = red[64 + lane], s2 = red[128 + lane], s3 = red[192 + lane];
+#pragma unroll
+  for (int q = 1; q < (NPIX == 256 ? 8 : 4); ++q) *reinterpret_cast<float4*>(out + 4 * q) = z;
+  const float4 s0 = red[pix], s1 = red[NPIX + pix], s2 = red[2 * NPIX + pix], s3 = red[3 * NPIX + pix];
   float v[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
   if (a.bias) {
 #pragma unroll
@@ -141,14 +209,14 @@ __global__ __launch_bounds__(256) void conv_tail_kernel(const TailArgs a) {
   *reinterpret_cast<float4*>(out) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// w [cout][cin][ks][ks] (PyTorch) -> wt [taps][cin_pad][4]: wt[(t * cin_pad + ci) * 4 + c] = w[n0 + c][ci][t] * scale[n0 + c] (zeros
-// beyond cout / cin); the same fp32 product as opp_pack_conv's folded BatchNorm scale
+// w [cout][cin][ks][ks] (PyTorch) -> wt [cin_pad / 32][taps][32][4]: wt[((g * taps + t) * 32 + (ci & 31)) * 4 + c] = w[n0 + c][ci][t] * scale[n0 + c]
+// (zeros beyond cout / cin); the same fp32 product as opp_pack_conv's folded BatchNorm scale
 __global__ __launch_bounds__(256) void pack_conv_tail_kernel(const float* __restrict__ w, const float* __restrict__ scale, int cout, int cin, int ks, int n0,
                                                              int cin_pad, float* __restrict__ wt) {
   const int taps = ks * ks;
   const int n = taps * cin_pad * 4;
   for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const int c = e & 3, ci = (e >> 2) % cin_pad, t = (e >> 2) / cin_pad;
+    const int c = e & 3, cl = (e >> 2) & 31, t = ((e >> 7) % taps), ci = (e >> 7) / taps * 32 + cl;
     const int co = n0 + c;
     float v = 0.f;
     if (co < cout && ci < cin) {
@@ -203,13 +271,24 @@ int opp_conv_tail(const OppGemm& g, const float* wt, int n0, int ncols, hipStrea
   a.res_sy = g.res_sy;
   a.res_sx = g.res_sx;
   a.act = g.act;
-  const int IW = (TP - 1) * g.stride + g.ksize;
-  const size_t lds = (size_t)(IW * IW * LS > 4 * 64 * 4 ? IW * IW * LS : 4 * 64 * 4) * sizeof(float);
-  const int tiles = opp_cdiv(g.Hout, TP) * opp_cdiv(g.Wout, TP);
+  const int th = 8;
+  const int iwx = (TW - 1) * g.stride + g.ksize, iwy = (th - 1) * g.stride + g.ksize;
+  const size_t stage = (size_t)iwx * iwy * LS + (size_t)g.ksize * g.ksize * 128, red = (size_t)4 * th * TW * 4;
+  const size_t lds = (stage > red ? stage : red) * sizeof(float);
+  const int tiles = opp_cdiv(g.Hout, th) * opp_cdiv(g.Wout, TW);
+  OPP_CHECK_ARG((size_t)g.Hin * g.Win * g.Cin < (1ull << 31), "conv_tail: image too large for 32-bit offsets");
   // algorithmic bytes: the input read once, the 32-column line of every output pixel written (the VALU-bound 4 x K multiply-adds per pixel
   // are 2 % of the layer's work)
   OppProfScope prof(OPP_PROF_CONV_TAIL, stream, (double)g.Bn * ((double)g.Hin * g.Win * g.Cin * 4.0 + (double)g.Hout * g.Wout * 128.0));
-  hipLaunchKernelGGL(conv_tail_kernel, dim3(tiles, g.Bn), dim3(256), lds, stream, a);
+  static OppLdsOnce once[4];               // per kernel variant and device (the stride-2 3 x 3 tile stages more than 64 KB)
+  auto launch = [&](void (*k)(const TailArgs), OppLdsOnce& o) {
+    opp_lds_opt_in(reinterpret_cast<const void*>(k), lds, o);
+    hipLaunchKernelGGL(k, dim3(tiles, g.Bn), dim3(256), lds, stream, a);
+  };
+  if (g.ksize == 3 && g.stride == 1) launch(conv_tail_kernel<3, 1>, once[0]);
+  else if (g.ksize == 3) launch(conv_tail_kernel<3, 2>, once[1]);
+  else if (g.stride == 1) launch(conv_tail_kernel<1, 1>, once[2]);
+  else launch(conv_tail_kernel<1, 2>, once[3]);
   OPP_CHECK_LAUNCH("conv_tail_kernel");
   return OPP_OK;
 }

@@ -182,6 +182,7 @@ class OnePosePlus_model(nn.Module):
         self.fpn_overlap = os.environ.get("OPP_FPN_OVERLAP", "1") != "0"
         self.skip_unused_fine_map = os.environ.get("OPP_SKIP_UNUSED_FINE_MAP", "0") == "1"
         self.fine_patch_max_matches = int(os.environ.get("OPP_FINE_PATCH_MAX", "1000"))
+        self.conv_tail = os.environ.get("OPP_CONV_TAIL", "0") == "1"
         self.fine_patch_pixels_per_match = 64      # patches only while M <= fine-map pixels / this (0 = no such rule; tests force the path)
         self._reset_runtime()
 
@@ -258,6 +259,15 @@ class OnePosePlus_model(nn.Module):
         decides then, or -- when the PREVIOUS forward of this module had more matches than the limit (consecutive frames of one object
         look alike) -- runs the dense branch inside the coarse call, beside the coarse level, as before.  Bit-identical results either way."""
         self.fine_patch_max_matches = max(0, int(n))
+        return self
+
+    def set_conv_tail(self, on):
+        """Opt-in (default off): the 196-channel convolutions as a 192-column MFMA body + a 4-column fp32 tail on the vector ALU
+        (include/opp_hip.h `opp_set_conv_tail`) instead of 224 / 256 padded MFMA columns.  Same parity bar; not faster."""
+        self.conv_tail = bool(on)
+        ctx = self._rt.get("ctx")
+        if ctx:
+            _lib.check(_lib.load().opp_set_conv_tail(ctx, 1 if self.conv_tail else 0), "opp_set_conv_tail")
         return self
 
     def set_score_two_sweep(self, mode):
@@ -368,6 +378,7 @@ class OnePosePlus_model(nn.Module):
             ccfg = self._c_config()
             _lib.check(lib.opp_create(ctypes.byref(ccfg), ctypes.byref(ctx)), "opp_create")
             rt["ctx"] = ctx
+            _lib.check(lib.opp_set_conv_tail(ctx, 1 if getattr(self, "conv_tail", False) else 0), "opp_set_conv_tail")
             rt["names"] = [lib.opp_weight_name(ctx, i).decode() for i in range(lib.opp_num_weights(ctx))]
         if rt["dirty"] or rt["packed"] is None or rt["packed"].device != device:
             sd = dict(self.named_parameters())

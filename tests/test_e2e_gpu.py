@@ -675,3 +675,33 @@ def test_match_driven_fine_branch_at_the_image_border(hw, window):
     assert int(((jy == 0) | (jx == 0) | (jy == hw[0] // 8 - 1) | (jx == wc - 1)).sum()) > 0, "no border match: the case tests nothing"
     for k in ("i_ids", "j_ids", "mconf", "expec_f", "mkpts_query_f"):
         assert torch.equal(fused[k], patches[k]), k
+
+
+def test_conv_tail_opt_in_meets_the_same_bar():
+    """`model.set_conv_tail(True)` (include/opp_hip.h `opp_set_conv_tail`; off by default): the eight 196-channel convolutions as a
+    192-column body on the 128 x 192 MFMA tile + their last 4 columns as fp32 FMA chains (csrc/conv_tail.hip: 1 x 1 / 3 x 3, stride 1 / 2,
+    same-tensor and bilinear residuals, the VALID patch convolutions of the match-driven fine branch).  Reference-generated goldens at the
+    bar of the default path: the high-confidence case end to end, a small full forward, and a train()-mode batch (raw weights, B = 2)."""
+    from tests import hip_ops as ops
+    name = "highconf_512x512_n3000"
+    cfg, sd, data = H.highconf_setup(name)
+    for patch_max in (0, 1 << 20):                   # dense fine map / per-match patches
+        m = ops.make_model(cfg, sd).set_conv_tail(True).set_fine_patch_max_matches(patch_max)
+        m.fine_patch_pixels_per_match = 0
+        out = ops.run_model(m, data)
+        H.assert_match_outputs(out, H.load_golden(name), where=name + " + conv tail")
+    plain = ops.run_model(ops.make_model(cfg, sd), data)
+    assert torch.equal(plain["i_ids"], out["i_ids"]) and not torch.equal(plain["conf_matrix"], out["conf_matrix"])   # (it is a different evaluation)
+    name = "e2e_96x64_n77_thr0"
+    cfg, sd, data = H.e2e_setup(name)
+    H.assert_match_outputs(ops.run_model(ops.make_model(cfg, sd).set_conv_tail(True), data), H.load_golden(name), where=name + " + conv tail")
+    name = "train_b2_128x128_n300"
+    cfg, sd, data = H.train_setup(name)
+    gold = H.load_golden(name)
+    model = ops.make_model(cfg, sd).set_conv_tail(True)
+    model.train()
+    model.train_randint = H.RecordedRandint([gold["randint_%d" % i] for i in range(int(gold["n_randint"]))])
+    d = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in data.items()}
+    with torch.no_grad():
+        model(d)
+    H.assert_train_outputs(d, model.state_dict(), gold, tol_bn=1e-4, where=name + " + conv tail")
