@@ -439,13 +439,14 @@ def run(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[precision],
             "data": "synthetic (seeded random image, descriptor bank and weights)",
-            "config": {"workload": "configs[1]: single object, %dx%d image x %d points, coarse-match only%s, B=1 per forward, "
+            "config": {"workload": "%s: single object, %dx%d image x %d points, %s, B=1 per forward, "
                                    "a step = %d forwards per GPU, %d forward(s) in flight per GPU on separate HIP streams, one object per GPU; image and "
                                    "descriptor banks resident in HBM; the image-independent work on the resident object (keypoint-MLP encoding of the "
                                    "bank, layer-0 self-attention of the 3D stream, its layer-1 projections and KV sums: 2.6 %% of the FLOPs, still counted "
                                    "in model_gflop_per_image) is cached per object -- `object_token_cache_off` is the leg without it; thr %.2f gives M = %d "
                                    "matches on these random weights (the conf matrix is still fully materialised)"
-                                   % (args.hw, args.hw, args.n_points, " + fine refine" if args.fine else "", ips, n_streams,
+                                   % ("configs[2] / [3] shape" if args.fine else "configs[1]", args.hw, args.hw, args.n_points,
+                                      "full coarse-to-fine (match-driven fine branch)" if args.fine else "coarse-match only", ips, n_streams,
                                       args.thr, matches_last),
                        "images_per_step": ips, "streams_per_gpu": n_streams,
                        "per_rank_images_per_s": per_rank_summary(devs), "gemm_precision": precision, "tile_policy": policy, "fpn_overlap": bool(overlap),

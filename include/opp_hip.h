@@ -379,6 +379,14 @@ int opp_fine_window_gather_backward(const float* grad_windows, int B, int Hf, in
                                     const long long* j_ids, int n_matches, int hc, int wc, int window, float* grad_feat_f,
                                     void* stream);
 
+/* FineMatching's expectation head on its own (utils/fine_matching.py:63-94: heatmap = softmax(<f3, win_r> / sqrt(C)), spatial expectation and
+ * the summed standard deviation) for the training graph, and its backward.  f3 [M][C] point tokens, win [M][window^2][C] window tokens, expec_f
+ * [M][3]; scratch_xy: 4 M floats.  Backward: grad_expec_f [M][3] -> grad_f3 [M][C], grad_win [M][window^2][C] (every element written). */
+int opp_fine_head_train_forward(const float* f3, const float* win, int n_matches, int window, int C, float* expec_f, float* scratch_xy,
+                                void* stream);
+int opp_fine_head_train_backward(const float* f3, const float* win, int n_matches, int window, int C, const float* grad_expec_f,
+                                 float* grad_f3, float* grad_win, void* stream);
+
 /* Ground-truth matrices of one training sample, formed on the device from the k assignment pairs
  * (OnePosePlusDataset.build_assignmatrix, src/datasets/OnePosePlus_dataset.py:174-236; the loader builds 229 MB per sample on the host
  * at N = 7000).  kp2d_coarse / kp2d_fine [n2d][2] fp32; assign [2][k] int64 (row 0: 2D keypoint index, row 1: padded 3D point index);

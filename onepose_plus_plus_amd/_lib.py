@@ -87,6 +87,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_fine_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "opp_fine_head_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "opp_fine_head_train_backward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "opp_build_assignmatrix": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "opp_set_fine_patch_buffers": (c_int, [c_void_p, c_void_p, c_void_p]),

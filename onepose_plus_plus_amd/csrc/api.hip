@@ -2311,6 +2311,24 @@ extern "C" int opp_dual_softmax_forward(const float* sim, int B, int N, int L, f
   return opp_dual_softmax_lse(sim, B, N, L, lse_row, lse_col, conf, ws, ws_bytes, (hipStream_t)stream);
 }
 
+// FineMatching._s2d_heatmap (utils/fine_matching.py:63-94) on its own, for the training graph: expec_f [M][3] from the point tokens f3 [M][C] and
+// the window tokens win [M][W * W][C]; its backward (d loss / d expec_f -> d f3, d win)
+extern "C" int opp_fine_head_train_forward(const float* f3, const float* win, int M, int window, int C, float* expec_f, float* scratch_xy, void* stream) {
+  OPP_CHECK_ARG(f3 && win && expec_f && scratch_xy && M >= 0 && window > 1, "fine_head_train_forward: bad argument");
+  if (M == 0) return OPP_OK;
+  // the inference kernel also forms mkpts_f = mkpts_c + offset: scratch_xy [2][M][2] holds a zero mkpts_c and receives the unused sum
+  if (hipMemsetAsync(scratch_xy, 0, (size_t)M * 2 * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    opp_set_error("fine_head_train_forward: memset failed");
+    return OPP_ERR_LAUNCH;
+  }
+  return opp_fine_head(f3, C, win, C, M, window, C, (float)(1.0 / sqrt((double)C)), scratch_xy, 1.f, nullptr, expec_f, scratch_xy + (size_t)M * 2, (hipStream_t)stream);
+}
+
+extern "C" int opp_fine_head_train_backward(const float* f3, const float* win, int M, int window, int C, const float* grad_expec_f, float* grad_f3,
+                                            float* grad_win, void* stream) {
+  return opp_fine_head_bwd(f3, C, win, C, M, window, C, (float)(1.0 / sqrt((double)C)), grad_expec_f, grad_f3, grad_win, (hipStream_t)stream);
+}
+
 extern "C" int opp_build_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int n2d, const long long* assign, int k, int N, int L, int w_c,
                                       float scale_x, float scale_y, float coarse_scale, short* conf_gt, float* fine_loc_gt, long long* keys, int* status,
                                       void* stream) {

@@ -340,19 +340,24 @@ __global__ __launch_bounds__(C) void linattn_small_pair_kernel(const float* __re
 // One block = one wave = one head of one chunk of kPairChunk tokens of ONE stream (grid = chunks x 8 heads,
 // >= 4 waves per CU at 5k points: the reduction is bound by loads in flight, not by the MFMA):
 //   KV_h[d][v] += sum_t K[t][h*32+d] * V[t][h*32+v]   ==  mfma_32x32x2(A = K^T, B = V), 2 tokens / MFMA
-// Both streams are covered by one launch; partials [chunk][h][d][v] are summed in fixed order
-// by linattn_reduce_pair_kernel (deterministic).
+// Both streams are covered by one launch.  A workgroup = four waves = four consecutive chunks of ONE stream: their accumulators are summed
+// through LDS in a fixed order ((w0 + w1) + (w2 + w3)), so one partial per 256 tokens leaves (r05: 36 instead of 142 partials at 4096 +
+// 5000 tokens -- the fixed-order merge behind it, linattn_reduce_pair_kernel, reads a quarter of the data).  Deterministic.
 // ---------------------------------------------------------------------------------------
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 constexpr int kPairChunk = 64;
-__global__ __launch_bounds__(64) void linattn_kv_mfma_kernel(const float* __restrict__ qkv, int ld, int len0, int len1,
-                                                              int chunks0, float* __restrict__ kv_part,
-                                                              float* __restrict__ ks_part) {
+constexpr int kPairGroup = 4;       // chunks (waves) per workgroup
+__global__ __launch_bounds__(256) void linattn_kv_mfma_kernel(const float* __restrict__ qkv, int ld, int len0, int len1,
+                                                               int groups0, float* __restrict__ kv_part,
+                                                               float* __restrict__ ks_part) {
   constexpr int C = 256, CHUNK = kPairChunk;
-  const int chunk = blockIdx.x;
-  const int stream = chunk >= chunks0 ? 1 : 0;
-  const int cidx = stream ? chunk - chunks0 : chunk;
+  __shared__ float acc_sh[kPairGroup][1024];
+  __shared__ float ks_sh[kPairGroup][32];
+  const int grp = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int stream = grp >= groups0 ? 1 : 0;
+  const int cidx = (stream ? grp - groups0 : grp) * kPairGroup + wave;      // chunk of the stream (past its end: an all-zero contribution)
   const int seg_len = stream ? len1 : len0;
   const int tok0 = stream ? len0 : 0;
   const int s_begin = cidx * CHUNK;
@@ -380,14 +385,21 @@ __global__ __launch_bounds__(64) void linattn_kv_mfma_kernel(const float* __rest
       ksum += kk[u];
     }
   }
-  float* kvp = kv_part + (size_t)chunk * (C * 32) + h * 1024;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
-    kvp[d * 32 + l31] = acc[r];
+    acc_sh[wave][d * 32 + l31] = acc[r];
   }
   const float tot = ksum + __shfl_xor(ksum, 32, 64);
-  if (half == 0) ks_part[(size_t)chunk * C + h * 32 + l31] = tot;
+  if (half == 0) ks_sh[wave][l31] = tot;
+  __syncthreads();
+  float* kvp = kv_part + (size_t)grp * (C * 32) + h * 1024;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = threadIdx.x + i * 256;
+    kvp[o] = (acc_sh[0][o] + acc_sh[1][o]) + (acc_sh[2][o] + acc_sh[3][o]);
+  }
+  if (threadIdx.x < 32) ks_part[(size_t)grp * C + h * 32 + threadIdx.x] = (ks_sh[0][threadIdx.x] + ks_sh[1][threadIdx.x]) + (ks_sh[2][threadIdx.x] + ks_sh[3][threadIdx.x]);
 }
 
 // out_kv [2][8192], out_ks [2][256] ; blockIdx.y = stream.  Block = 64 outputs x 4 chunk groups (group g sums
@@ -585,12 +597,14 @@ size_t opp_linattn_pair_scratch_floats(int len0, int len1) {
 // qkv [len0+len1][ld] with Q | K | V column blocks of 256.  kv [2][8192], ks [2][256].
 int opp_linattn_kv_pair(const float* qkv, int ld, int len0, int len1, float* kv, float* ks, float* scratch,
                         hipStream_t stream) {
-  const int c0 = opp_cdiv(len0, kPairChunk), c1 = opp_cdiv(len1, kPairChunk);
+  // partials: one per workgroup = per kPairGroup chunks of a stream
+  const int c0 = opp_cdiv(opp_cdiv(len0, kPairChunk), kPairGroup), c1 = opp_cdiv(opp_cdiv(len1, kPairChunk), kPairGroup);
   float* kvp = scratch;
   float* ksp = scratch + (size_t)(c0 + c1) * 8192;
-  {  // algorithmic bytes: K and V of every token read once + the chunk partials written
+  if (c0 + c1 == 0) return OPP_OK;
+  {  // algorithmic bytes: K and V of every token read once + the partials written
     OppProfScope prof(OPP_PROF_LINATTN_KV, stream, (double)(len0 + len1) * 512.0 * 4.0 + (double)(c0 + c1) * (8192 + 256) * 4.0);
-    hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(64), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
+    hipLaunchKernelGGL(linattn_kv_mfma_kernel, dim3(c0 + c1, 8), dim3(256), 0, stream, qkv, ld, len0, len1, c0, kvp, ksp);
   }
   {  // algorithmic bytes: every chunk partial read once, KV / Ksum of both streams written
     OppProfScope prof(OPP_PROF_LINATTN_REDUCE, stream, (double)(c0 + c1 + 2) * (8192 + 256) * 4.0);

@@ -115,6 +115,88 @@ __global__ __launch_bounds__(256) void fine_head_kernel(const float* __restrict_
   }
 }
 
+// Backward of fine_head_kernel's expectation (the training step; fine_matching.py:63-94 under autograd): one wave per match.
+//   sim_r = temp <f3, win_r>, p = softmax(sim), ex = sum gx p, ey = sum gy p, vx = max(sum gx^2 p - ex^2, 1e-10), std = sqrt(vx) + sqrt(vy)
+//   g = d loss / d (ex, ey, std):  a_r = gx_r Dex + gy_r Dey + gx_r^2 Dxx + gy_r^2 Dyy  with  Dxx = g_std / (2 sqrt(vx)) [var >= 1e-10],
+//   Dex = g_ex - 2 ex Dxx (y alike);  d sim_r = p_r (a_r - sum_s p_s a_s);  d f3 = temp sum_r d sim_r win_r;  d win_r = temp d sim_r f3
+__global__ __launch_bounds__(256) void fine_head_bwd_kernel(const float* __restrict__ f3, int ld3, const float* __restrict__ win, int ldw, int M, int Wwin,
+                                                            int C, float temp, const float* __restrict__ gexp, float* __restrict__ gf3,
+                                                            float* __restrict__ gwin) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float sim_sh[4][64];
+  const int wv = threadIdx.x >> 6, grp = lane >> 4, sub = lane & 15;
+  const int WW = Wwin * Wwin;
+  const bool live = m < M;
+  const int mm = live ? m : M - 1;
+  const float* f = f3 + (size_t)mm * ld3;
+  for (int r0 = 0; r0 < WW; r0 += 4) {
+    const int r = r0 + grp;
+    float acc = 0.f;
+    if (r < WW) {
+      const float* w = win + ((size_t)mm * WW + r) * ldw;
+      for (int c = sub * 4; c < C; c += 64) {
+        const float4 w4 = *reinterpret_cast<const float4*>(w + c);
+        const float4 f4 = *reinterpret_cast<const float4*>(f + c);
+        acc = fmaf(f4.x, w4.x, acc);
+        acc = fmaf(f4.y, w4.y, acc);
+        acc = fmaf(f4.z, w4.z, acc);
+        acc = fmaf(f4.w, w4.w, acc);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0 && r < WW) sim_sh[wv][r] = acc;
+  }
+  __syncthreads();
+  float sim = -INFINITY;
+  if (lane < WW) sim = temp * sim_sh[wv][lane];
+  float mx = sim;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float e = lane < WW ? expf(sim - mx) : 0.f;
+  float tot = e;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+  const float p = e / tot;
+  float gx = 0.f, gy = 0.f;
+  if (lane < WW) {
+    const int ky = lane / Wwin, kx = lane - ky * Wwin;
+    gx = ((float)kx / (float)(Wwin - 1) - 0.5f) * 2.f;
+    gy = ((float)ky / (float)(Wwin - 1) - 0.5f) * 2.f;
+  }
+  float ex = gx * p, ey = gy * p, exx = gx * gx * p, eyy = gy * gy * p;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ex += __shfl_xor(ex, o, 64);
+    ey += __shfl_xor(ey, o, 64);
+    exx += __shfl_xor(exx, o, 64);
+    eyy += __shfl_xor(eyy, o, 64);
+  }
+  const float g_ex = gexp[3 * mm + 0], g_ey = gexp[3 * mm + 1], g_sd = gexp[3 * mm + 2];
+  const float varx = exx - ex * ex, vary = eyy - ey * ey;
+  const float dxx = varx >= 1e-10f ? g_sd * 0.5f / sqrtf(varx) : 0.f;     // torch.clamp(min) passes the gradient where var >= min
+  const float dyy = vary >= 1e-10f ? g_sd * 0.5f / sqrtf(vary) : 0.f;
+  const float dex = g_ex - 2.f * ex * dxx, dey = g_ey - 2.f * ey * dyy;
+  const float a = gx * dex + gy * dey + gx * gx * dxx + gy * gy * dyy;
+  float pa = p * a;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pa += __shfl_xor(pa, o, 64);
+  const float dsim = lane < WW ? temp * (p * (a - pa)) : 0.f;               // includes the temperature factor of sim
+  if (!live) return;
+  // lanes over channels from here on: d f3[c] = sum_r dsim_r win[r][c],  d win[r][c] = dsim_r f3[c]
+  for (int c = lane; c < C; c += 64) {
+    const float fc = f[c];
+    float acc = 0.f;
+    for (int r = 0; r < WW; ++r) {
+      const float dr = __shfl(dsim, r, 64);
+      acc = fmaf(dr, win[((size_t)m * WW + r) * ldw + c], acc);
+      gwin[((size_t)m * WW + r) * ldw + c] = dr * fc;
+    }
+    gf3[(size_t)m * ld3 + c] = acc;
+  }
+}
+
 // ---- match-driven fine branch (api.hip: opp_fine_patches) -------------------------------------------------------------------
 // In eval mode the last three convolutions of the FPN fine branch (layer1_outconv, layer1_outconv2: backbone/resnet.py:154-157) are
 // consumed only through the W x W windows around the M matches (fine_preprocess.py:41-55), so they are evaluated on a per-match patch
@@ -230,6 +312,15 @@ int opp_fine_points_gather(const float* bank, int n_points, const long long* i_i
   if (M <= 0) return OPP_OK;
   hipLaunchKernelGGL(fine_points_gather_kernel, dim3(M), dim3(128), 0, stream, bank, n_points, i_ids, C, f3, ld3);
   OPP_CHECK_LAUNCH("fine_points_gather_kernel");
+  return OPP_OK;
+}
+
+int opp_fine_head_bwd(const float* f3, int ld3, const float* win, int ldw, int M, int Wwin, int C, float temp, const float* gexp, float* gf3, float* gwin,
+                      hipStream_t stream) {
+  if (M <= 0) return OPP_OK;
+  OPP_CHECK_ARG(f3 && win && gexp && gf3 && gwin && Wwin * Wwin <= 64 && Wwin > 1 && C % 4 == 0 && ldw % 4 == 0 && ld3 % 4 == 0, "fine head backward: bad argument");
+  hipLaunchKernelGGL(fine_head_bwd_kernel, dim3(opp_cdiv(M, 4)), dim3(256), 0, stream, f3, ld3, win, ldw, M, Wwin, C, temp, gexp, gf3, gwin);
+  OPP_CHECK_LAUNCH("fine_head_bwd_kernel");
   return OPP_OK;
 }
 

@@ -242,6 +242,8 @@ int opp_fine_points_gather(const float* bank, int n_points, const long long* i_i
 int opp_fine_gather(const float* feat, int Hf, int Wf, int ldf, const float* bank, int n_points,
                     const long long* i_ids, const long long* j_ids, int M, int wc, int stride, int Wwin, int C,
                     float* win, int ldw, float* f3, int ld3, hipStream_t stream);
+int opp_fine_head_bwd(const float* f3, int ld3, const float* win, int ldw, int M, int Wwin, int C, float temp, const float* gexp, float* gf3, float* gwin,
+                      hipStream_t stream);
 int opp_fine_head(const float* f3, int ld3, const float* win, int ldw, int M, int Wwin, int C, float temp,
                   const float* mkpts_c, float base_scale, const float* qscale, float* expec, float* mkpts_f,
                   hipStream_t stream);

@@ -14,7 +14,8 @@ the step runs in a PyTorch (MIOpen / rocBLAS) operator:
   `HipCoarseMatch`      score GEMM + dual softmax + mutual-nearest-neighbour selection = the inference kernels (opp_coarse_match);
                         backward = dual-softmax backward (csrc/loss.hip) + the two feature gradients on the Linear-backward GEMMs
   `HipFineGather`       5 x 5 windows of the fine map; backward scatters (csrc/train_misc.hip)
-PyTorch supplies the tape (autograd), elementwise glue (residual adds, ReLU, the 25-cell expectation head) and index plumbing.
+  `HipFineHead`         FineMatching's expectation head (heatmap softmax, spatial expectation, std) forward + backward (csrc/fine.hip, r05)
+PyTorch supplies the tape (autograd), elementwise glue (residual adds, ReLU) and index plumbing.
 
 The helpers `_linear` / `_layer_norm` / `_kpt_encoding` / `_linear_attention` / `_encoder_layer` / `_transformer` / `DualSoftmax` fall
 back to plain torch ops for CPU tensors (hp = None): that is how tests/torch_graph_ref.py -- the functional restatement of the whole
@@ -489,6 +490,43 @@ class HipFineGather(torch.autograd.Function):
         return d.view(ctx.shape), None, None, None
 
 
+class HipFineHead(torch.autograd.Function):
+    """FineMatching._s2d_heatmap (utils/fine_matching.py:63-94): expec_f [M, 3] = (spatial expectation x, y of softmax(<f0, window> / sqrt(C)), summed
+    standard deviation) from the point tokens f0 [M, C] and the window tokens win [M, W * W, C]; forward = the inference kernel, backward =
+    `opp_fine_head_train_backward` (csrc/fine.hip) -- the last piece of the fine level that ran as ATen elementwise ops."""
+
+    @staticmethod
+    def forward(ctx, f0, win):
+        from . import _lib
+        lib = _lib.load()
+        dev = f0.device
+        f0c, wc = f0.to(torch.float32).contiguous(), win.to(torch.float32).contiguous()
+        M, WW, C = wc.shape
+        W = int(round(WW ** 0.5))
+        expec = torch.empty((M, 3), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(4 * M, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_fine_head_train_forward(f0c.data_ptr(), wc.data_ptr(), M, W, C, expec.data_ptr(), scratch.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream), "opp_fine_head_train_forward")
+        ctx.save_for_backward(f0c, wc)
+        return expec
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        lib = _lib.load()
+        f0c, wc = ctx.saved_tensors
+        dev = f0c.device
+        M, WW, C = wc.shape
+        W = int(round(WW ** 0.5))
+        gc = g.to(torch.float32).contiguous()
+        gf, gw = torch.empty_like(f0c), torch.empty_like(wc)
+        with torch.cuda.device(dev):
+            _lib.check(lib.opp_fine_head_train_backward(f0c.data_ptr(), wc.data_ptr(), M, W, C, gc.data_ptr(), gf.data_ptr(), gw.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), "opp_fine_head_train_backward")
+        return gf, gw
+
+
 def graph_precision(model):
     """`hp` of the device graph from the module's gemm_precision"""
     return {"bf16x3": 2, "fp32": 0}[model.gemm_precision]
@@ -528,6 +566,8 @@ def fine_level_graph(model, p, feat_f, bank_f, b_ids, i_ids, j_ids, B, hf, wf, h
     if fcfg["enable"]:
         g3, win = _transformer(p, "loftr_fine", fcfg, g3.contiguous(), win, None, hp)
     f0 = g3[:, g3.shape[1] // 2, :]                                                   # fine_matching.py:63-68
+    if win.is_cuda and Cf % 4 == 0 and W * W <= 64 and W > 1 and win.shape[0] > 0:
+        return HipFineHead.apply(f0, win)                                             # heatmap, expectation, std: forward and backward in HIP
     heat = torch.softmax((f0[:, None, :] * win).sum(-1) / Cf ** 0.5, dim=1)           # 'mc,mrc->mr' as multiply + reduce
     lin = (torch.linspace(0, W - 1, W, device=heat.device) / (W - 1) - 0.5) * 2
     gx, gy = lin.view(1, W).expand(W, W).reshape(-1), lin.view(W, 1).expand(W, W).reshape(-1)

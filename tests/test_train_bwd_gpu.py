@@ -596,3 +596,37 @@ def test_training_graph_with_a_frozen_pretrained_backbone(tmp_path):
         e = {k: d[k][:1] for k in data if k != "conf_matrix_gt"}
         model(e)
     assert torch.isfinite(e["conf_matrix"]).all()
+
+
+@pytest.mark.parametrize("M,W", [(1, 5), (37, 5), (1203, 5), (10, 7), (6, 3)])
+def test_fine_head_backward_vs_fp64(M, W):
+    """`HipFineHead` (FineMatching._s2d_heatmap, utils/fine_matching.py:63-94 under autograd): expec_f and the gradients of the point / window
+    tokens against fp64 autograd of the reference formula (softmax heatmap over the W x W cells, kornia's normalised grid, spatial expectation,
+    summed sqrt(clamp(var, 1e-10))), incl. sharply peaked heatmaps whose variance sits on the clamp."""
+    from onepose_plus_plus_amd.train_autograd import HipFineHead
+    g = torch.Generator().manual_seed(M * 10 + W)
+    C = 128
+    f0 = torch.randn(M, C, generator=g)
+    win = torch.randn(M, W * W, C, generator=g)
+    if M > 2:
+        win[0] *= 0.0                                   # uniform heatmap
+        win[1, 3] = f0[1] * 40.0                        # one cell takes all the mass: var below the clamp
+    ge = torch.randn(M, 3, generator=g)
+    a, b = f0.cuda().requires_grad_(True), win.cuda().requires_grad_(True)
+    out = HipFineHead.apply(a, b)
+    (out * ge.cuda()).sum().backward()
+    fd, wd = f0.double().requires_grad_(True), win.double().requires_grad_(True)
+    heat = torch.softmax(torch.einsum("mc,mrc->mr", fd, wd) / C ** 0.5, dim=1)
+    lin = (torch.linspace(0, W - 1, W, dtype=torch.float64) / (W - 1) - 0.5) * 2
+    gx, gy = lin.view(1, W).expand(W, W).reshape(-1), lin.view(W, 1).expand(W, W).reshape(-1)
+    coords = torch.stack([(gx * heat).sum(-1), (gy * heat).sum(-1)], dim=-1)
+    grid = torch.stack([gx, gy], dim=-1)
+    var = torch.sum(grid[None] ** 2 * heat[:, :, None], dim=1) - coords ** 2
+    ref = torch.cat([coords, torch.sum(torch.sqrt(torch.clamp(var, min=1e-10)), -1)[:, None]], -1)
+    (ref * ge.double()).sum().backward()
+    assert float((out.detach().cpu().double() - ref.detach()).abs()[:, :2].max()) < 1e-5
+    ok = var.detach().min(1).values > 1e-6              # rows on the clamp: the derivative of sqrt there is ~1e5 and discontinuous
+    for got, want in ((a.grad.cpu().double(), fd.grad), (b.grad.cpu().double(), wd.grad)):
+        scale = float(want[ok].abs().max()) if ok.any() else 1.0
+        assert float((got[ok] - want[ok]).abs().max()) <= 2e-5 * max(scale, 1e-6), (M, W)
+        assert torch.isfinite(got).all()
