@@ -1744,9 +1744,14 @@ int coarse_match_impl(opp_ctx* c, const float* f3, const float* f2, int n, int h
     return OPP_ERR_WORKSPACE;
   }
   if (two_sweep) {
-    // both operands pre-split once (7.7 + 6.3 MB)
-    OPP_TRY(opp_b3_split(f2, f2_split, (size_t)L * C, s));
-    OPP_TRY(opp_b3_split(f3, f3_split, (size_t)n * C, s));
+    // both operands pre-split once (7.7 + 6.3 MB); in the forward they are one token buffer [L + n][C] and the two split buffers are adjacent in
+    // the workspace: one launch (r05)
+    if (f3 == f2 + (size_t)L * C && f3_split == f2_split + split_floats((size_t)L * C, sprec)) {
+      OPP_TRY(opp_b3_split(f2, f2_split, (size_t)(L + n) * C, s));
+    } else {
+      OPP_TRY(opp_b3_split(f2, f2_split, (size_t)L * C, s));
+      OPP_TRY(opp_b3_split(f3, f3_split, (size_t)n * C, s));
+    }
     if (c->cfg.score_two_sweep == 2)   // one sweep of the split-operand GEMM (statistics + score matrix), conf formed in place
       return opp_dual_softmax_ss_single(f3_split, f2_split, C, n, L, wc, 1.0f / (float)C, (float)((double)c->cfg.match_temperature + 1e-4),
                                         c->query_mask, c->cfg.match_thr, c->cfg.match_border_rm, kpts, base_scale, qscale, conf, stats, scratch,

@@ -112,9 +112,9 @@ __global__ void col_reduce_kernel(const float* __restrict__ part, int chunks, in
 // ---- merge of the per-tile (max, sum exp) partials produced by the score GEMM epilogue -----------
 // rows: part [N][T] ; cols: part [T][L] ; out max / sum with the global max as reference
 // rows: 8 lanes per row, lane u takes tiles u, u+8, ...; pairwise combine in a fixed butterfly order
-__global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
-                                                        float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
-  const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+__device__ __forceinline__ void row_merge_body(int bid, const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
+                                               float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
+  const int i = bid * 32 + (threadIdx.x >> 3);
   const int u = threadIdx.x & 7;
   float m = -INFINITY, s = 0.f;
   if (i < N) {
@@ -133,12 +133,15 @@ __global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict_
     if (orcp != nullptr) orcp[i] = __frcp_rn(s);
   }
 }
-// columns: block = 64 columns x 4 tile groups (group g takes tiles g, g+4, ...), combined through LDS in group order
-__global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
+__global__ __launch_bounds__(256) void row_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int N, int T,
                                                         float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
-  __shared__ float red[4][64];
+  row_merge_body(blockIdx.x, pmax, psum, N, T, omax, osum, orcp);
+}
+// columns: block = 64 columns x 4 tile groups (group g takes tiles g, g+4, ...), combined through LDS in group order
+__device__ __forceinline__ void col_merge_body(int bid, float (*red)[64], const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
+                                               float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
   const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
+  const int j = bid * 64 + c;
   float m = -INFINITY;
   if (j < L)
     for (int t = gq; t < T; t += 4) m = fmaxf(m, pmax[(size_t)t * L + j]);
@@ -157,6 +160,20 @@ __global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict_
     osum[j] = tot;
     if (orcp != nullptr) orcp[j] = __frcp_rn(tot);
   }
+}
+__global__ __launch_bounds__(256) void col_merge_kernel(const float* __restrict__ pmax, const float* __restrict__ psum, int L, int T,
+                                                        float* __restrict__ omax, float* __restrict__ osum, float* __restrict__ orcp) {
+  __shared__ float red[4][64];
+  col_merge_body(blockIdx.x, red, pmax, psum, L, T, omax, osum, orcp);
+}
+// both merges of the single-sweep matcher in ONE launch (r05): blocks [0, row_blocks) merge the row partials, the rest the column partials
+__global__ __launch_bounds__(256) void rowcol_merge_kernel(int row_blocks, const float* __restrict__ rpmax, const float* __restrict__ rpsum, int Nr, int Tr,
+                                                           float* __restrict__ romax, float* __restrict__ rosum, float* __restrict__ rorcp,
+                                                           const float* __restrict__ cpmax, const float* __restrict__ cpsum, int Nc, int Tc,
+                                                           float* __restrict__ comax, float* __restrict__ cosum, float* __restrict__ corcp) {
+  __shared__ float red[4][64];
+  if ((int)blockIdx.x < row_blocks) row_merge_body(blockIdx.x, rpmax, rpsum, Nr, Tr, romax, rosum, rorcp);      // block-uniform branch
+  else col_merge_body(blockIdx.x - row_blocks, red, cpmax, cpsum, Nc, Tc, comax, cosum, corcp);
 }
 // column max over `chunks` partial rows [chunks][L] (max is order-independent): 64 columns x 4 chunk groups
 __global__ __launch_bounds__(256) void col_max_reduce_kernel(const float* __restrict__ part, int chunks, int L,
@@ -631,8 +648,8 @@ int opp_dual_softmax_ss_single(const void* f3s, const void* f2s, int C, int N, i
   g.stat_colmax = g.stat_rowsum + (size_t)L * tp;
   g.stat_colsum = g.stat_colmax + (size_t)tl * N;
   OPP_TRY(opp_gemm_ss(g, stream));
-  hipLaunchKernelGGL(row_merge_kernel, dim3(opp_cdiv(L, 32)), dim3(256), 0, stream, g.stat_rowmax, g.stat_rowsum, L, tp, cmax, csum, crcp);
-  hipLaunchKernelGGL(col_merge_kernel, dim3(opp_cdiv(N, 64)), dim3(256), 0, stream, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum, (float*)nullptr);
+  hipLaunchKernelGGL(rowcol_merge_kernel, dim3(opp_cdiv(L, 32) + opp_cdiv(N, 64)), dim3(256), 0, stream, opp_cdiv(L, 32), g.stat_rowmax, g.stat_rowsum, L, tp,
+                     cmax, csum, crcp, g.stat_colmax, g.stat_colsum, N, tl, rmax, rsum, (float*)nullptr);
   return opp_dual_softmax_select(conf, N, L, wc, thr, border, kpts, base_scale, qscale, stats, -1, scratch, i_ids, j_ids, mconf, mkpts_c, mkpts_3d,
                                  count, stream);
 }

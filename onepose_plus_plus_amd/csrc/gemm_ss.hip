@@ -107,6 +107,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_kernel(const OppGemmSS g) {
   // under the other's prologue / epilogue).  blockIdx is scalar: the branch is wave-uniform, as s_setprio requires.
   if (g.prio_mode == 1 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(1);
   if (g.prio_mode == 2 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(3);
+  // De-phasing of the two workgroups that share a CU (r05).  They are dispatched together and, left alone, stay in lock step: both in the K
+  // loop (each at half the matrix-pipe rate), then both in the epilogue (matrix pipe idle) -- a tile then costs loop + epilogue instead of
+  // max(loop, epilogue).  The first generation of workgroups (the first 2 x 256) is shifted by roughly half a tile: the workgroup whose
+  // wave 0 sits in an odd hardware wave slot (HW_ID.wave_id: the second of the two residents of its SIMD) sleeps before its prologue; every
+  // later workgroup inherits the phase of the slot it is dispatched into.  Modes 3 / 4 / 5: 8 / 16 / 24 k cycles.
+  if (g.prio_mode >= 3 && blockIdx.x < g.dephase_blocks) {
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      *flag = (int)(hw & 1u);
+    }
+    __syncthreads();
+    const int odd = *flag;
+    __syncthreads();
+    if (odd)
+      for (int i = 0; i < g.prio_mode - 2; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only -- every output is indexed by tile coordinates): an XCD gets
   // a contiguous range of a linear order that walks STRIPS of RS row panels column by column (row fastest).  The ~64 tiles an
@@ -582,6 +600,14 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
   {
     static const int prio_env = getenv("OPP_SS_PRIO") ? atoi(getenv("OPP_SS_PRIO")) : 0;
     g.prio_mode = prio_env;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    static int cus_cached = 0;
+    if (!cus_cached) {
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      cus_cached = cus > 0 ? cus : 256;
+    }
+    g.dephase_blocks = 2 * cus_cached;       // the first generation: two workgroups per CU
   }
   OPP_CHECK_ARG(g.A && g.B && g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm_ss: bad operands / K %% 32 (M %d N %d K %d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.lda % 16 == 0 && g.ldb % 16 == 0 && g.lda >= g.K * 6 && g.ldb >= g.K * 6, "gemm_ss: operand row strides are bytes, >= 6 K, 16-byte multiples");

@@ -330,6 +330,11 @@ class HipBackbone(torch.autograd.Function):
         ctx.ptrs, ctx.keep = model._rt["ptrs"], model._rt["keep"]       # the weight table the tape's forward ran on (kept alive)
         ctx.geom = (B, H, W)
         ctx.shapes = [tuple(p.shape) for p in params]
+        # the backward reads the image and the parameters IN PLACE through raw pointers (convolution weights for the input gradients, gamma
+        # for the BatchNorm backward): remember their version counters so that an in-place update between forward and backward -- an
+        # optimiser step before a delayed backward, a reused input buffer -- raises like PyTorch's saved-tensor check instead of silently
+        # producing gradients of another function (r04 advisor finding)
+        ctx.versions = [(t, t._version) for t in (img,) + tuple(params)]
         return feat_c, feat_f
 
     @staticmethod
@@ -342,6 +347,11 @@ class HipBackbone(torch.autograd.Function):
         if c is not ctx.c_ctx or ctx.tape is None:
             raise RuntimeError("HipBackbone.backward: the module's runtime was re-created (set_gemm_precision / .to()) or the graph was "
                                "already differentiated between this step's forward and backward")
+        for t, v in ctx.versions:
+            if t._version != v:
+                raise RuntimeError("HipBackbone.backward: one of the variables needed for gradient computation has been modified by an inplace "
+                                   "operation (the image or a backbone parameter changed between this step's forward and its backward: "
+                                   "version %d, expected %d)" % (t._version, v))
         dev = ctx.img.device
         B, H, W = ctx.geom
         ptrs, n = ctx.ptrs

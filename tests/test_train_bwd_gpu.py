@@ -630,3 +630,25 @@ def test_fine_head_backward_vs_fp64(M, W):
         scale = float(want[ok].abs().max()) if ok.any() else 1.0
         assert float((got[ok] - want[ok]).abs().max()) <= 2e-5 * max(scale, 1e-6), (M, W)
         assert torch.isfinite(got).all()
+
+
+def test_backbone_backward_refuses_parameters_modified_in_place():
+    """`HipBackbone` reads the image and the backbone parameters in place during the backward: an in-place update between forward and
+    backward must raise like PyTorch's saved-tensor version check, not give gradients of another function (r04 advisor finding)."""
+    from onepose_plus_plus_amd import train_autograd as TA
+    from onepose_plus_plus_amd.config import default_config
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    from tests import hip_ops as ops
+    cfg = default_config()
+    model = ops.make_model(cfg, make_state_dict(cfg, 4))
+    model.train()
+    img = torch.rand(1, 1, 64, 64).cuda()
+    lib, c = model._ensure_ready(torch.device("cuda:0"))
+    fc, ff = TA.backbone_node(model, lib, c, img)
+    with torch.no_grad():
+        model.backbone.conv1.weight.mul_(1.01)               # e.g. an optimiser step before a delayed backward
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        (fc.sum() + ff.sum()).backward()
+    fc, ff = TA.backbone_node(model, lib, c, img)             # untouched: the backward runs
+    (fc.sum() + ff.sum()).backward()
+    assert torch.isfinite(model.backbone.conv1.weight.grad).all()
