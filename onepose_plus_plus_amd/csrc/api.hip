@@ -83,6 +83,7 @@ struct EncLayerDesc {
   float *sqkv = nullptr, *smerge = nullptr, *s1 = nullptr, *s2 = nullptr;   // fp16x2 {scale, 1/scale} per matrix
   // bf16x3 only: merge / mlp.0 / mlp.2 once more in the fragment-major order of the fused layer kernel (enc_chain.hip)
   void *fmerge = nullptr, *f1 = nullptr, *f2 = nullptr;
+  void* fqkv = nullptr;   // coarse level: q | k | v [3 C][C] in the same order -- folded into the PREVIOUS layer's kernel (enc_layer64.hip, r05)
 };
 
 }  // namespace
@@ -393,6 +394,7 @@ size_t plan_pack(opp_ctx* c, void* base) {
         e.fmerge = a.raw(opp_frag_b3_bytes(d, d));
         e.f1 = a.raw(opp_frag_b3_bytes(2 * d, 2 * d));
         e.f2 = a.raw(opp_frag_b3_bytes(d, 2 * d));
+        e.fqkv = d == 256 ? a.raw(opp_frag_b3_bytes(3 * d, d)) : nullptr;
       }
     }
   };
@@ -479,6 +481,7 @@ extern "C" int opp_pack_weights(opp_ctx* c, const float* const* w, int n, void* 
       OPP_TRY(copy_f(e.b1, w[q + 7], d, s));
       OPP_TRY(copy_f(e.g2, w[q + 8], d, s));
       OPP_TRY(copy_f(e.b2, w[q + 9], d, s));
+      if (e.fqkv) OPP_TRY(opp_pack_frag_b3(e.wqkv, 3 * d, d, e.fqkv, s));     // (e.wqkv is still the fp32 concatenation here)
       if (e.fmerge) {
         OPP_TRY(opp_pack_frag_b3(w[q + 3], d, d, e.fmerge, s));
         OPP_TRY(opp_pack_frag_b3(w[q + 4], 2 * d, 2 * d, e.f1, s));
@@ -1520,7 +1523,10 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
     const int l1_qkv = (prefix_mode == OPP_PREFIX_USE && li < 2) ? 0 : len1;
     const int l1_lay = (prefix_mode == OPP_PREFIX_USE && li == 0) ? 0 : len1;
     const bool make_tail = prefix_mode == OPP_PREFIX_MAKE && li == 1;     // projection + KV of the 3D stream into the prefix, then stop
-    {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
+    // the fused coarse path folds layer li + 1's projection into layer li's kernel: only layer 0 launches the GEMM
+    static const bool fold_env = !(getenv("OPP_QKV_FOLD") && getenv("OPP_QKV_FOLD")[0] == '0');     // A/B switch of the tools
+    const bool fold_path = fold_env && fusion == 2 && h2 == OPP_PREC_BF16X3 && n_seg == 1 && C == 256 && D == 32 && e.fmerge && e.fqkv;
+    if (!(fold_path && li > 0)) {  // q/k/v projections of both streams in one GEMM; phi(q), phi(k), v / S fused (transformer.py:76-79)
       OppGemm g;
       g.nonfinite = t_status_flag;
       g.tile_policy = t_tile_policy;
@@ -1567,6 +1573,12 @@ int transformer_impl(const std::vector<EncLayerDesc>& layers, const int* is_cros
         ch.q1 = pre->qkv1;
         ch.kv1 = pre->kv1;
         ch.ks1 = pre->ks1;
+      }
+      if (fold_path && li + 1 < layers.size() && layers[li + 1].fqkv) {   // this kernel also projects its output rows for layer li + 1
+        ch.wq_next = layers[li + 1].fqkv;
+        ch.qkv_out = b.qkv;
+        ch.qkv_out1 = (prefix_mode == OPP_PREFIX_MAKE && li == 0) ? pre->qkv1 : nullptr;
+        ch.qmask = mask0;
       }
       ch.msg = b.msg;
       ch.ldm = C;

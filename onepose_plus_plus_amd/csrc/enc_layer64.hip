@@ -158,7 +158,21 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
       float y[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) y[i] = opp_ln_affine(v[r][i], mean[r], rstd[r], gmv[i], btv[i]);
-      if constexpr (MODE == 0) {
+      if constexpr (MODE != 0) {                 // MODE 1 / 2: out[row] = x[row] + y (global); MODE 2 keeps the sum as the next operand tile
+        if (lr < nrows) {
+          const vec_t xr = *reinterpret_cast<const vec_t*>(a.X + (size_t)(row0 + lr) * a.ldx + lane * 4);
+          vec_t o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = xr[i] + y[i];
+          *reinterpret_cast<vec_t*>(a.out + (size_t)(row0 + lr) * a.ldo + lane * 4) = o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = o[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) y[i] = 0.f;
+        }
+      }
+      if constexpr (MODE != 1) {
         char* g = A + lr * SA + ((lane * 4) >> 3) * 48 + ((lane * 4) & 7) * 2;   // lane owns k = 4 lane .. 4 lane + 3
 #pragma unroll
         for (int i = 0; i < 4; i += 2) {
@@ -167,14 +181,6 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
           *reinterpret_cast<unsigned*>(g + i * 2) = hi;
           *reinterpret_cast<unsigned*>(g + 16 + i * 2) = mid;
           *reinterpret_cast<unsigned*>(g + 32 + i * 2) = lo;
-        }
-      } else {
-        if (lr < nrows) {
-          const vec_t xr = *reinterpret_cast<const vec_t*>(a.X + (size_t)(row0 + lr) * a.ldx + lane * 4);
-          vec_t o;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = xr[i] + y[i];
-          *reinterpret_cast<vec_t*>(a.out + (size_t)(row0 + lr) * a.ldo + lane * 4) = o;
         }
       }
     }
@@ -314,12 +320,50 @@ __global__ __launch_bounds__(NT) void enc_layer64_kernel(const OppEncChain a) {
   }
 
   // ---- 6. norm2 -> x + . (transformer.py:92-94) ------------------------------------------------------------------------
+  const bool fold = a.wq_next != nullptr;             // (kernel argument: uniform)
 #pragma unroll
   for (int rh = 0; rh < 2; ++rh) {
     stage(out[rh][0], wave * 32, false);
     __syncthreads();
-    layernorm_rows(a.g2, a.b2, a.eps_ln, I1{}, rh * 32);
+    if (fold) layernorm_rows(a.g2, a.b2, a.eps_ln, I2{}, rh * 32);     // ... and the finished rows become the operand tile of step 7
+    else layernorm_rows(a.g2, a.b2, a.eps_ln, I1{}, rh * 32);
     __syncthreads();
+  }
+  if (!fold) return;
+
+  // ---- 7. the NEXT layer's q | k | v projection of this tile (transformer.py:76-79 of layer i + 1; r05): 24 column tiles of 32, three per
+  //         wave, K = 256; same six-product sequence and epilogue arithmetic as the stand-alone GEMM (gemm_mfma.hip, OPP_ACT_QKV) ---------
+  float* qdst = (stream && a.qkv_out1 != nullptr) ? a.qkv_out1 + (size_t)(cidx * R64) * (3 * C) : a.qkv_out + (size_t)row0 * (3 * C);
+  const float vdiv = (float)seg_len;                  // values / v_length of the stream that produces them (linear_attention.py:55-56)
+  auto store_qkv = [&](const f32x16& t, int rb, int tile) {
+    const int col = tile * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (row < nrows) {
+        float v = t[r];
+        if (col < 2 * C) v = v > 0.f ? v + 1.f : __expf(v);      // elu(x) + 1, linear_attention.py:10-11
+        else v = v / vdiv;
+        if (stream == 0 && a.qmask != nullptr) v *= a.qmask[row0 + row];   // padded image tokens: q, k, v rows -> 0 (linear_attention.py:49-53)
+        qdst[(size_t)row * (3 * C) + col] = v;
+      }
+    }
+  };
+  {
+    f32x16 acc[2][2];
+    zero2(acc);
+    gemm(I2{}, I3{}, I0{}, I16{}, I16{}, a.wq_next, wave * 3, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) store_qkv(acc[i][j], i * 32, wave * 3 + j);
+  }
+  {
+    f32x16 acc[2][1];
+    zero2(acc);
+    gemm(I1{}, I4{}, I0{}, I16{}, I16{}, a.wq_next, wave * 3 + 2, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store_qkv(acc[i][0], i * 32, wave * 3 + 2);
   }
 }
 
@@ -332,10 +376,11 @@ int opp_enc_layer64(const OppEncChain& a, hipStream_t stream) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   OPP_CHECK_ARG(al16(a.X) && al16(a.out) && al16(a.q) && a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.ldq % 4 == 0 && al16(a.g1) && al16(a.b1) &&
                     al16(a.g2) && al16(a.b2) && al16(a.wm) && al16(a.w1) && al16(a.w2) && al16(a.q1), "enc_layer64: operands must be 16-byte aligned");
+  OPP_CHECK_ARG(a.wq_next == nullptr || (a.qkv_out != nullptr && al16(a.wq_next)), "enc_layer64: folded projection needs its output buffer");
   static OppLdsOnce lds_once;            // per device (opp_common.h)
   opp_lds_opt_in(reinterpret_cast<const void*>(enc_layer64_kernel), kLds64, lds_once);
   const int tiles = opp_cdiv(a.len0, R64) + opp_cdiv(a.len1, R64);
-  OppProfScope prof(OPP_PROF_ENC_CHAIN, stream, 2.0 * (double)(a.len0 + a.len1) * (7.0 * C * C + 32.0 * C));
+  OppProfScope prof(OPP_PROF_ENC_CHAIN, stream, 2.0 * (double)(a.len0 + a.len1) * ((a.wq_next ? 10.0 : 7.0) * C * C + 32.0 * C));
   hipLaunchKernelGGL(enc_layer64_kernel, dim3(tiles), dim3(NT), kLds64, stream, a);
   OPP_CHECK_LAUNCH("enc_layer64_kernel");
   return OPP_OK;

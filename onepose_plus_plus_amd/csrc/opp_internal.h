@@ -93,6 +93,14 @@ struct OppEncChain {
   const float* q1 = nullptr;
   const float* kv1 = nullptr;
   const float* ks1 = nullptr;
+  // enc_layer64 only, optional (r05): the NEXT layer's q | k | v projection folded into this layer's tail -- the finished output tile is
+  // in LDS as bf16x3 operands anyway.  wq_next: [3 C][C] fragment-major (opp_pack_frag_b3); qkv_out [len0 + len1][3 C] receives
+  // phi(q) | phi(k) | v / S of every row (may be the buffer `q` points into: a workgroup reads and writes only its own rows), stream-1 rows
+  // into qkv_out1 [len1][3 C] instead when given; qmask [len0] = query_image_mask of the image tokens (rows of stream 0) or null
+  const void* wq_next = nullptr;
+  float* qkv_out = nullptr;
+  float* qkv_out1 = nullptr;
+  const float* qmask = nullptr;
   int cross = 0;
   float eps_attn = 1e-6f;
   // fragment-major bf16x3 weights (opp_pack_frag_b3): merge [C][C], mlp.0 [2C][2C], mlp.2 [C][2C]
