@@ -12,12 +12,17 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/final_bench_driver.json 2> gp
 python tools/smi_trace.py --out gpurun_out/final_smi -- python bench.py --steps 200 --warmup 5 --cpu-seconds 0 --no-legs --no-roofline > gpurun_out/final_smi.log 2>&1
 python tools/train_probe.py > gpurun_out/final_train_probe.txt 2> gpurun_out/final_train_probe.err
 python tools/conv_bwd_bench.py 4 > gpurun_out/final_conv_bwd_bench.txt 2>/dev/null
+python tools/fine_leg.py > gpurun_out/final_fine_leg.json 2> gpurun_out/final_fine_leg.err
+python tools/matcher_bench.py --reps 60 > gpurun_out/final_matcher_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # single stream, fine branch on the same stream, the tiles of the timed region: the condition of bench.py's roofline pass
 OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --images-per-step 1 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_fine -o fine -- python $GRAFT_REPO_ROOT/tools/fine_profile.py > $GRAFT_REPO_ROOT/gpurun_out/final_fine.log 2>&1
-cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv gpurun_out/final_fine/*trace.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_train -o tr -- python $GRAFT_REPO_ROOT/tools/train_trace.py 4 > $GRAFT_REPO_ROOT/gpurun_out/final_train.log 2>&1
+cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv gpurun_out/final_fine/*trace.csv gpurun_out/final_train/*trace.csv
+find gpurun_out/final_s1 gpurun_out/final_s3 gpurun_out/final_fine gpurun_out/final_train -name "*trace.csv" -delete
 rm -rf gpurun_out/final_pmc/FETCH_SIZE/*trace.csv gpurun_out/final_pmc/WRITE_SIZE/*trace.csv gpurun_out/final_pmc_mfma/mfma/*trace.csv
 (timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -15) > gpurun_out/final_gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.txt 2>&1
 ls gpurun_out/final_s1 gpurun_out/final_s3 gpurun_out/final_fine gpurun_out/final_pmc
