@@ -544,6 +544,11 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     # interval of a kernel that does nothing = what the rocprofv3 kernel trace shows as its duration, 3.6 us in round 4)
     _lib.check(lib.opp_profile_empty_kernel(400, ctypes.byref(ek), torch.cuda.current_stream(dev).cuda_stream), "profile_empty_kernel")
     empty_kernel_us = ek.value if 0.5 < ek.value < 20.0 else EMPTY_KERNEL_US
+    # what the event pair adds to a REAL launch: a 10-us spin kernel timed per launch between its own events and back to back between one pair
+    # (an empty kernel over-corrects: its pair reading is mostly launch latency that real kernels overlap)
+    cp, cb = ctypes.c_double(), ctypes.c_double()
+    _lib.check(lib.opp_profile_event_calibration(200, 10.0, ctypes.byref(cp), ctypes.byref(cb), torch.cuda.current_stream(dev).cuda_stream), "event_calibration")
+    event_extra_us = min(max(cp.value - cb.value, 0.0), max(event_pair_us - empty_kernel_us, 0.0))
     for cfg_id, kind, tile, what in GEMM_SYMBOLS:
         spid = 0 if (kind == 2 and precision == "fp16x2") else pid      # fp16x2: the score GEMM stays fp32
         ms, fl, n = prof_run(lib, _lib, torch, dev, step, cfg_id, kind, nsteps)
@@ -584,7 +589,7 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     # trace is EMPTY_KERNEL_US), so event_pair_us - EMPTY_KERNEL_US of every reading is not the kernel: 30 ... 60 % of a sub-15-us
     # launch, 5 ... 15 % of a 40-us one.  `frac` stays the raw reading; `frac_event_corrected` is what the kernel trace shows.
     for m in meas:
-        t = max(m["avg_launch_us"] - max(event_pair_us - empty_kernel_us, 0.0), 0.25 * m["avg_launch_us"])
+        t = max(m["avg_launch_us"] - event_extra_us, 0.25 * m["avg_launch_us"])
         m["avg_launch_us_event_corrected"] = round(t, 2)
         m["frac_event_corrected"] = round(m["frac"] * m["avg_launch_us"] / t, 4)
     # one entry per KERNEL SYMBOL (what a rocprofv3 trace lists): launch shapes of the same template instance are merged, their own
@@ -606,7 +611,8 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
                   "avg_launch_us": round(tot_us / n, 2), "avg_launch_us_event_corrected": round(tot_us_c / n, 2),
                   "us_per_forward": round(us_f, 1), "alg_gflop_per_launch": round(fl / n, 3), "achieved": round(ach, 2),
                   "frac": round(ach / a["peak"], 4), "frac_event_corrected": round(ach / a["peak"] * tot_us / tot_us_c, 4),
-                  "traffic": None, "launch_shapes": shapes,
+                  "traffic": a.get("traffic") or b.get("traffic"),      # (the PMC summary keys by template + workgroup count: both shapes have 256)
+                  "launch_shapes": shapes,
                   "kernel": a["kernel"] + " -- all launch shapes of this symbol: unsplit (1/4-resolution stage) + 4 K slices (1/8-resolution stage)"})
         meas.remove(b)
     meas.sort(key=lambda m: -m["us_per_forward"])
@@ -624,8 +630,10 @@ def roofline_leg(lib, _lib, torch, dev, step, precision, nsteps):
     roof["other_kernels"] = meas[1:]
     roof["event_pair_us"] = round(event_pair_us, 2)
     roof["empty_kernel_us"] = round(empty_kernel_us, 2)
-    roof["event_correction"] = ("frac_event_corrected: launch time minus (event_pair_us - empty_kernel_us) = the reading of an empty kernel between "
-                                "two events minus its own back-to-back duration, both measured in this run")
+    roof["event_extra_us"] = round(event_extra_us, 2)
+    roof["event_calibration"] = {"spin_kernel_pair_us": round(cp.value, 2), "spin_kernel_back_to_back_us": round(cb.value, 2)}
+    roof["event_correction"] = ("frac_event_corrected: launch time minus event_extra_us = what a 10-us spin kernel reads between its own event pair "
+                                "minus its back-to-back launch interval, measured in this run (event_pair_us / empty_kernel_us: the same for an empty kernel)")
     return roof
 
 

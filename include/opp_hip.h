@@ -495,6 +495,9 @@ int opp_profile_start(int tile_cfg, int kind, int capacity_launches);
 int opp_profile_event_overhead(int launches, double* mean_us, void* stream);
 /* The empty kernel's own duration: `launches` of them back to back between ONE event pair; *mean_us = elapsed / launches. */
 int opp_profile_empty_kernel(int launches, double* mean_us, void* stream);
+/* What an event pair adds to the reading of a real launch: a spin kernel of ~spin_us timed per launch between its own event pair (*pair_us)
+ * and back to back between one pair (*b2b_us = its duration + the inter-kernel gap); pair_us - b2b_us is what bench.py subtracts. */
+int opp_profile_event_calibration(int launches, double spin_us, double* pair_us, double* b2b_us, void* stream);
 int opp_profile_stop(double* total_ms, double* total_work, int* launches);
 
 #ifdef __cplusplus

@@ -48,6 +48,7 @@ SIGNATURES = {
     "opp_source_hash": (c_char_p, []),
     "opp_profile_event_overhead": (c_int, [c_int, POINTER(ctypes.c_double), c_void_p]),
     "opp_profile_empty_kernel": (c_int, [c_int, POINTER(ctypes.c_double), c_void_p]),
+    "opp_profile_event_calibration": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),
     "opp_create": (c_int, [POINTER(OppConfig), POINTER(c_void_p)]),
     "opp_destroy": (None, [c_void_p]),
     "opp_set_status_flag": (c_int, [c_void_p, c_void_p]),

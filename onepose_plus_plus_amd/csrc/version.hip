@@ -13,6 +13,12 @@ extern "C" const char* opp_source_hash(void) { return OPP_SRC_HASH; }
 // after, on the launch stream), which measures what the event pair itself adds to a short launch.
 namespace {
 __global__ void opp_empty_kernel() {}
+// one wave busy for `ticks` of the constant-rate wall clock (100 MHz on gfx950: 100 ticks = 1 us): a kernel of KNOWN length for the calibration below
+__global__ void opp_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {
+  }
+}
 }  // namespace
 
 extern "C" int opp_profile_event_overhead(int launches, double* mean_us, void* stream_) {
@@ -52,8 +58,55 @@ extern "C" int opp_profile_event_overhead(int launches, double* mean_us, void* s
   return rc;
 }
 
-// The empty kernel's own duration: `launches` of them back to back between ONE event pair -> the launch-to-launch interval of a kernel
-// that does nothing, which is what a rocprofv3 kernel trace reports as its duration.  bench.py subtracts it from the event-pair reading above.
+// What an event pair adds to the reading of a REAL launch (r05): a spin kernel of ~spin_us is timed both ways on the same stream -- every launch
+// between its own event pair (*pair_us = mean reading) and `launches` of them back to back between ONE pair (*b2b_us = launch-to-launch
+// interval = the kernel's duration + the inter-kernel gap, i.e. slightly MORE than a kernel trace shows for it).  pair_us - b2b_us is therefore a
+// slightly conservative estimate of the part of an event reading that is not the kernel; bench.py subtracts it for `frac_event_corrected`.
+// (An EMPTY kernel is a poor probe: its pair reading is dominated by launch latency that real kernels overlap -- it over-corrects by ~2 us.)
+extern "C" int opp_profile_event_calibration(int launches, double spin_us, double* pair_us, double* b2b_us, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OPP_CHECK_ARG(launches > 0 && launches <= 2048 && spin_us > 0.0 && spin_us <= 1000.0 && pair_us && b2b_us, "profile_event_calibration: bad argument");
+  const long long ticks = (long long)(spin_us * 100.0);
+  const int n = launches + 4;
+  hipEvent_t* ev = new hipEvent_t[2 * n + 2];
+  int made = 0;
+  for (; made < 2 * n + 2; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) break;
+  int rc = OPP_OK;
+  if (made < 2 * n + 2) {
+    opp_set_error("profile_event_calibration: hipEventCreate failed");
+    rc = OPP_ERR_LAUNCH;
+  } else {
+    for (int i = 0; i < n; ++i) {
+      (void)hipEventRecord(ev[2 * i], stream);
+      hipLaunchKernelGGL(opp_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+      (void)hipEventRecord(ev[2 * i + 1], stream);
+    }
+    (void)hipEventRecord(ev[2 * n], stream);
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(opp_spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+    (void)hipEventRecord(ev[2 * n + 1], stream);
+    if (hipEventSynchronize(ev[2 * n + 1]) != hipSuccess) {
+      opp_set_error("profile_event_calibration: hipEventSynchronize failed");
+      rc = OPP_ERR_LAUNCH;
+    } else {
+      double total = 0.0;
+      for (int i = 4; i < n; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        total += ms;
+      }
+      *pair_us = total * 1e3 / launches;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev[2 * n], ev[2 * n + 1]);
+      *b2b_us = (double)ms * 1e3 / launches;
+    }
+  }
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+// The empty kernel's own back-to-back interval (kept for reference beside the calibration above).
 extern "C" int opp_profile_empty_kernel(int launches, double* mean_us, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OPP_CHECK_ARG(launches > 0 && launches <= 65536 && mean_us, "profile_empty_kernel: bad argument");

@@ -16,8 +16,9 @@ python tools/fine_leg.py > gpurun_out/final_fine_leg.json 2> gpurun_out/final_fi
 python tools/matcher_bench.py --reps 60 > gpurun_out/final_matcher_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # single stream, fine branch on the same stream, the tiles of the timed region: the condition of bench.py's roofline pass
-OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 25 --warmup 5 --images-per-step 1 --cpu-seconds 0 --no-legs --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 30 --warmup 6 --images-per-step 1 --cpu-seconds 0 --no-legs > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
+OPP_FPN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s1 -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 5 --images-per-step 4 --cpu-seconds 0 --no-legs --no-roofline --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/final_s1.log 2>&1
+# the timed region itself (default streams, throughput tiles; no roofline pass: its 500+ single-stream forwards would dominate the table)
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_s3 -o s3 -- python $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 6 --images-per-step 4 --cpu-seconds 0 --no-legs --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/final_s3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_fine -o fine -- python $GRAFT_REPO_ROOT/tools/fine_profile.py > $GRAFT_REPO_ROOT/gpurun_out/final_fine.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_train -o tr -- python $GRAFT_REPO_ROOT/tools/train_trace.py 4 > $GRAFT_REPO_ROOT/gpurun_out/final_train.log 2>&1
 cd $GRAFT_REPO_ROOT; rm -f gpurun_out/final_s1/*trace.csv gpurun_out/final_s3/*trace.csv gpurun_out/final_fine/*trace.csv gpurun_out/final_train/*trace.csv
