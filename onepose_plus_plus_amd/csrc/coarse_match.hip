@@ -287,25 +287,31 @@ __global__ __launch_bounds__(256) void conf_kernel(float* __restrict__ S, int N,
 
 // Register-resident variant for L <= KMAX * 256 (L % 4 == 0): a lane keeps its confidences of the current row
 // in registers (the tie count needs no second read of the row) and a running column maximum over the wave's
-// rows; the four waves then merge their maxima with ONE LDS max per column each.
+// rows; the waves then merge their maxima with ONE LDS max per column each.
+// r05: balanced grid.  The first version ran cdiv(N, 16) blocks of 4 waves x 4 rows (313 blocks at N = 5000 on 256 CUs: 57 CUs
+// swept 32 rows, the rest 16, and the launch lasted as long as the 32).  Now the grid is at most kConfGrid blocks of 8 waves
+// (register use admits one per CU), block b owns rows b, b + grid, b + 2 grid, ... (19 or 20 of them at N = 5000) and wave w of
+// it takes every eighth of those -- every CU streams the same number of rows and has 8 rows of loads in flight.  Row results
+// do not depend on who computes them and max is order-independent: bit-identical outputs.
+constexpr int kConfGrid = 256;
+constexpr int kConfWaves = 8;
 template <int KMAX>
-__global__ __launch_bounds__(256) void conf_reg_kernel(float* __restrict__ S, int N, int L,
+__global__ __launch_bounds__(kConfWaves * 64) void conf_reg_kernel(float* __restrict__ S, int N, int L,
                                                        const float* __restrict__ rmax, const float* __restrict__ rsum,
                                                        const float* __restrict__ cmax, const float* __restrict__ csum,
                                                        float* __restrict__ row_cmax, int* __restrict__ row_arg,
                                                        int* __restrict__ row_ties, float* __restrict__ col_part) {
   extern __shared__ unsigned colmax_bits[];
   const int lane = threadIdx.x & 63;
-  for (int j = threadIdx.x; j < L; j += 256) colmax_bits[j] = 0u;
+  const int wave = threadIdx.x >> 6;
+  for (int j = threadIdx.x; j < L; j += kConfWaves * 64) colmax_bits[j] = 0u;
   __syncthreads();
   float cmx[KMAX][4];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k)
 #pragma unroll
     for (int e = 0; e < 4; ++e) cmx[k][e] = 0.f;
-  for (int rr = 0; rr < kConfRows; ++rr) {
-    const int row = (blockIdx.x * kConfRows + rr) * 4 + (threadIdx.x >> 6);
-    if (row >= N) break;      // wave-uniform
+  for (int row = (int)blockIdx.x + (int)gridDim.x * wave; row < N; row += (int)gridDim.x * kConfWaves) {      // wave-uniform
     float* s = S + (size_t)row * L;
     const float rm = rmax[row], rrs = 1.0f / rsum[row];
     float best = -1.f;
@@ -365,10 +371,14 @@ __global__ __launch_bounds__(256) void conf_reg_kernel(float* __restrict__ S, in
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < L; j += 256) col_part[(size_t)blockIdx.x * L + j] = __uint_as_float(colmax_bits[j]);
+  for (int j = threadIdx.x; j < L; j += kConfWaves * 64) col_part[(size_t)blockIdx.x * L + j] = __uint_as_float(colmax_bits[j]);
 }
 
 // ---- selection + ordered compaction: single block ------------------------------------------
+// (r05, measured and removed: a one-pass variant -- thread t owns cdiv(N, 1024) consecutive rows, all per-row loads issued together, one
+// block scan -- took 14.9 us against this kernel's 13.0 at N = 5000 with 3080 survivors: the scattered output stores dominate, not the
+// barriers; and a variant that merged the column maxima in the same launch behind an arrival ticket took 39.6 us against 6.4 + 13:
+// the agent-scope fences cost more than the launch they save.)
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ conf, int N, int L, int wc,
                                                       const float* __restrict__ row_cmax, const int* __restrict__ row_arg,
                                                       const int* __restrict__ row_ties, const float* __restrict__ col_cmax,
@@ -536,12 +546,25 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
   const bool fuse_cmax = (size_t)L * 4 <= 64 * 1024;
   const size_t conf_lds = fuse_cmax ? (size_t)L * 4 : 0;
   float* cpart = fuse_cmax ? part : nullptr;
+  auto select = [&]() {
+    hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, S, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr,
+                       border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
+  };
   if (vec4 && fuse_cmax && L <= 16 * 256)
   {
-    OppProfScope prof(OPP_PROF_CONF, stream, (double)N * (double)L * 8.0);   // score matrix read + confidence matrix written
-    hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
+    // balanced grid of 8-wave blocks (<= cblocks, so the partial rows fit the scratch sized for the 4-wave kernels)
+    const int rblocks = cblocks < kConfGrid ? cblocks : kConfGrid;
+    {
+      OppProfScope prof(OPP_PROF_CONF, stream, (double)N * (double)L * 8.0);   // score matrix read + confidence matrix written
+      hipLaunchKernelGGL(conf_reg_kernel<16>, dim3(rblocks), dim3(kConfWaves * 64), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties,
+                         cpart);
+    }
+    hipLaunchKernelGGL(col_max_reduce_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, part, rblocks, L, col_cmax);
+    select();
+    OPP_CHECK_LAUNCH("coarse match kernels");
+    return OPP_OK;
   }
-  else if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
+  if (vec4) hipLaunchKernelGGL(conf_kernel<4>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
   else hipLaunchKernelGGL(conf_kernel<1>, dim3(cblocks), dim3(256), conf_lds, stream, S, N, L, rmax, rsum, cmax, crcp, row_cmax, row_arg, row_ties, cpart);
   if (fuse_cmax) {
     hipLaunchKernelGGL(col_max_reduce_kernel, dim3(opp_cdiv(L, 64)), dim3(256), 0, stream, part, cblocks, L, col_cmax);
@@ -549,8 +572,7 @@ int opp_dual_softmax_select(float* S, int N, int L, int wc, float thr, int borde
     hipLaunchKernelGGL(col_partial_kernel<0>, cgrid, dim3(256), 0, stream, S, N, L, 128, (const float*)nullptr, part);
     hipLaunchKernelGGL(col_reduce_kernel<0>, lgrid, dim3(256), 0, stream, part, chunks, L, col_cmax, (float*)nullptr);
   }
-  hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, stream, S, N, L, wc, row_cmax, row_arg, row_ties, col_cmax, thr,
-                     border, kpts, base_scale, qscale, i_ids, j_ids, mconf, mkpts_c, mkpts_3d, count);
+  select();
   OPP_CHECK_LAUNCH("coarse match kernels");
   return OPP_OK;
 }

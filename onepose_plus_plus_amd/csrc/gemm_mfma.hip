@@ -62,8 +62,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // a 192-column tile (tuning builds: 196 = 192 + a tail) has 4.5 weight pieces per thread: the upper half of the workgroup loads zeros
   // for its fifth piece and does not store it
   constexpr bool kBFrac = H3 && (BN * 12) % NT != 0;
+  // 224-column tile (r05: the 196(->224)-channel layers in ONE column tile, 7 sub-tiles of 32 columns on 2 x 4 waves): the waves with
+  // wn = 0 own 4 sub-tiles, those with wn = 1 own 3, and the wave -> (wm, wn) map puts one of each on every SIMD (waves w and w + 4 share
+  // SIMD w % 4), so every matrix pipe runs 7 sub-tiles per k-step where the 128 x 256 tile runs 8.  The 32 x 128 wave tile only fits the
+  // 256 registers of a two-waves-per-SIMD kernel with FOUR operand fragment sets instead of six: kRing (chunk_ring below).
+  constexpr bool kRing = H3 && kRagged;
   static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
-  static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 || BN == 192 : (BN * 8) % NT == 0), "load split");
+  static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 || BN == 192 || BN == 224 : (BN * 8) % NT == 0), "load split");
 
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (ABL == 9 || ABL > 90) ts0 = __builtin_readcyclecounter();
@@ -74,8 +79,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = __builtin_amdgcn_readfirstlane(wave / WAVES_N);
-  const int wn = __builtin_amdgcn_readfirstlane(wave % WAVES_N);
+  const int wm = __builtin_amdgcn_readfirstlane(kRing ? wave % WAVES_M : wave / WAVES_N);
+  const int wn = __builtin_amdgcn_readfirstlane(kRing ? wave / WAVES_M : wave % WAVES_N);
   bool tile_ok[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) tile_ok[j] = kRagged ? (wn * TN + j < NT32) : true;
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // so the matrix pipe never waits for a global load, an LDS write or the barrier.
   float4 ga[DEPTH][A_LD], gb[DEPTH][B_LD];   // DEPTH chunks of global prefetch in registers
   // fp32 uses sets 0,1 ; fp16x2 (0,1) = hi/lo of step 0, (2,3) of step 1 ; bf16x3 (0,1,2) = hi/mid/lo of step 0, (3,4,5) of step 1
-  float4 fa[H3 ? 6 : 4][TM], fb[H3 ? 6 : 4][TN];
+  // (kRing: four sets -- hi of the even k16-step, hi of the odd one, mid, lo -- see chunk_ring)
+  float4 fa[(H3 && !kRing) ? 6 : 4][TM], fb[(H3 && !kRing) ? 6 : 4][TN];
   float4 da[A_LD], db[B_LD];   // ablation 5 only: load sink that is never consumed in the loop
 
 #pragma unroll
@@ -418,8 +424,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   store_lds(0, ga[0], gb[0]);
   __syncthreads();
   read_frags(0, 0, fa[0], fb[0]);
-  if (H2 || H3) read_frags(0, 1, fa[1], fb[1]);
-  if constexpr (H3) read_frags(0, 2, fa[2], fb[2]);
+  if constexpr (kRing) {
+    read_frags(0, 1, fa[2], fb[2]);
+    read_frags(0, 2, fa[3], fb[3]);
+  } else {
+    if (H2 || H3) read_frags(0, 1, fa[1], fb[1]);
+    if constexpr (H3) read_frags(0, 2, fa[(H3 && !kRing) ? 2 : 0], fb[(H3 && !kRing) ? 2 : 0]);
+  }
 
   // The chunk body has no branches: the waitcnt pass can prove that the chunk c+1 registers are
   // the OLDEST loads in flight and waits with a counted vmcnt instead of draining the freshly
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // terms are <= 2^-26 |a||b|): 6/16 of the fp32 MFMA cycles, operands carried exactly ------
   auto as_b8 = [](const float4& v) { return *reinterpret_cast<const bf16x8*>(&v); };
   // products [p0, p1) of step `st` (fragment sets 3*st + {0 hi, 1 mid, 2 lo}), smallest terms first
+  constexpr int kH6 = (H3 && !kRing) ? 3 : 0;        // offset of the second step's fragment sets (six-set scheme)
   auto mfma_b3 = [&](int st, int p0, int p1, auto&& between) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
     constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if (tile_ok[j])
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[(H3 ? 3 : 0) * st + PA[pr]][i]), as_b8(fb[(H3 ? 3 : 0) * st + PB[pr]][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[kH6 * st + PA[pr]][i]), as_b8(fb[kH6 * st + PB[pr]][j]), acc[i][j], 0, 0, 0);
           between(n);
           ++n;
         }
@@ -573,9 +585,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     const int B0 = lb, B1 = lb ^ 1;
     advance();
     if (ABL != 94) {
-      read_frags(B0, 3, fa[H3 ? 3 : 0], fb[H3 ? 3 : 0]);
-      read_frags(B0, 4, fa[H3 ? 4 : 0], fb[H3 ? 4 : 0]);
-      read_frags(B0, 5, fa[H3 ? 5 : 0], fb[H3 ? 5 : 0]);
+      read_frags(B0, 3, fa[kH6], fb[kH6]);
+      read_frags(B0, 4, fa[kH6 ? 4 : 0], fb[kH6 ? 4 : 0]);
+      read_frags(B0, 5, fa[kH6 ? 5 : 0], fb[kH6 ? 5 : 0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_b3(0, 0, 6, [&](int n) {                    // step 0 + prefetch of chunk c+DEPTH, one load per slot
@@ -602,10 +614,85 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     if (ABL != 94) {
       read_frags(B1, 0, fa[0], fb[0]);
       read_frags(B1, 1, fa[1], fb[1]);
-      read_frags(B1, 2, fa[2], fb[2]);
+      read_frags(B1, 2, fa[kH6 ? 2 : 0], fb[kH6 ? 2 : 0]);
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_b3(1, 4, 6, nothing);                       // step 1 hi*mid + hi*hi cover the barrier + LDS latency
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- bf16x3 chunk on FOUR fragment sets (kRing): set 0 = hi of k16-step 0, set 1 = hi of step 1, set 2 = mid, set 3 = lo of the
+  // step being multiplied.  The product order of chunk_h3 (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi per step: the accumulation
+  // sequence every tile shares) frees lo after the second product and mid after the fifth, so the NEXT step's lo / mid are read into
+  // the same registers there, and the next step's hi into the other hi set:
+  //   step 0:  read hi1 | P0 P1 | read lo1 | P2 P3 P4 | read mid1 | P5          (+ the global prefetch of chunk c+2, one load per slot)
+  //   step 1:  P0 P1 P2 (+ the LDS hand-over of chunk c+1) | barrier | read hi0' lo0' of chunk c+1 | P3 P4 | read mid0' | P5
+  // Every read is issued >= 12 MFMAs ahead of its first use; the barrier sits under the last three products as in chunk_h3.
+  auto mfma_ring = [&](int hs, int p0, int p1, int n0, auto&& between) {
+    int n = n0;
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr) {
+      if (pr < p0 || pr >= p1) continue;
+      // A part of product pr: lo hi mid mid hi hi ; B part: hi lo mid hi mid hi  (PA / PB of mfma_b3) -> ring sets: hi = hs, mid = 2, lo = 3
+      const int sa = (pr == 0) ? 3 : (pr == 2 || pr == 3) ? 2 : hs;
+      const int sb = (pr == 1) ? 3 : (pr == 2 || pr == 4) ? 2 : hs;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (tile_ok[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[sa & 3][i]), as_b8(fb[sb & 3][j]), acc[i][j], 0, 0, 0);
+          between(n);
+          ++n;
+        }
+    }
+  };
+  constexpr int kSlotsR0 = 6 * TM * TN;                   // step 0: all six products carry the prefetch
+  constexpr int kStrideR0 = kSlotsR0 / kItems > 0 ? kSlotsR0 / kItems : 1;
+  constexpr int kSlotsR1 = 3 * TM * TN;                   // step 1: the first three carry the LDS hand-over
+  constexpr int kStrideR1 = kSlotsR1 / kItems > 0 ? kSlotsR1 / kItems : 1;
+  auto chunk_ring = [&](auto set, int lb) {
+    constexpr int P = decltype(set)::value;
+    constexpr int PN = (P + 1) % DEPTH;
+    const int B0 = lb, B1 = lb ^ 1;
+    auto pre = [&](int n) {
+      if (n % kStrideR0 == 0 && n / kStrideR0 < kItems) {
+        load_item(n / kStrideR0, ga[P], gb[P]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    advance();
+    read_frags(B0, 3, fa[1], fb[1]);                  // hi of step 1
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(0, 0, 2, 0, pre);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(B0, 5, fa[3], fb[3]);                  // lo of step 1 over the (dead) lo of step 0
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(0, 2, 5, 2 * TM * TN, pre);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(B0, 4, fa[2], fb[2]);                  // mid of step 1 over the (dead) mid of step 0
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(0, 5, 6, 5 * TM * TN, pre);
+#pragma unroll
+    for (int i = kSlotsR0 / kStrideR0; i < kItems; ++i) load_item(i, ga[P], gb[P]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(1, 0, 3, 0, [&](int n) {                // step 1, first three products + LDS hand-over of chunk c+1
+      if (n % kStrideR1 == 0 && n / kStrideR1 < kItems) {
+        store_item(n / kStrideR1, B1, ga[PN], gb[PN]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+#pragma unroll
+    for (int i = kSlotsR1 / kStrideR1; i < kItems; ++i) store_item(i, B1, ga[PN], gb[PN]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_frags(B1, 0, fa[0], fb[0]);                  // chunk c+1: hi of step 0 (set 0 is dead since step 0's last product)
+    read_frags(B1, 2, fa[3], fb[3]);                  //            lo of step 0 (lo of step 1 is dead after its second product)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(1, 3, 5, 0, nothing);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(B1, 1, fa[2], fb[2]);                  //            mid of step 0 over the (dead) mid of step 1
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_ring(1, 5, 6, 0, nothing);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -616,7 +703,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   if (NT == 512 && (g.xcd_swizzle & 2) && __builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
   // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
   for (int c = 0; c < nk; c += DEPTH) {
-    if constexpr (H3) {
+    if constexpr (kRing) {
+      chunk_ring(std::integral_constant<int, 0>{}, c & 1);
+      if (DEPTH > 1) chunk_ring(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+    } else if constexpr (H3) {
       chunk_h3(std::integral_constant<int, 0>{}, c & 1);
       if (DEPTH > 1) chunk_h3(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
       if (DEPTH > 2) chunk_h3(std::integral_constant<int, 2 % DEPTH>{}, (c + 2) & 1);
@@ -1046,8 +1136,8 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
   // 128 x 192 on 8 waves (32 x 96 per wave, 219 registers, 133 KB of LDS): the 192-column body of the 196-channel layers, whose last 4
   // columns come from conv_tail.hip (round 5; config 24)
-  constexpr bool kTuning192 = BM == 128 && BN == 192 && NT == 512 && PREC == OPP_PREC_BF16X3;
-  constexpr bool ok = (PREC == OPP_PREC_FP32 && BN != 192) ||
+  constexpr bool kTuning192 = BM == 128 && (BN == 192 || BN == 224) && NT == 512 && PREC == OPP_PREC_BF16X3;   // (and the 224-column ring tile)
+  constexpr bool ok = (PREC == OPP_PREC_FP32 && BN != 192 && BN != 224) ||
                       (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64) || (PREC == OPP_PREC_FP16X2 && BM == 128 && BN == 128)) &&
                        (BN == 128 || BN == 64 || BN == 256 || kTuning192) &&
                        (PREC != OPP_PREC_BF16X3 || (BN * 12) % NT == 0 || kTuning192) && (PREC != OPP_PREC_BF16X3 || BM * BN / NT <= 64 || kTuning192));
@@ -1268,11 +1358,14 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       struct Cand { int cfg, bm, bn, wpc, chunk, fixed; };
       // (24: 128 x 192, for outputs that are whole 192-column tiles -- the body of a 196-channel layer: measured 228 us against 272 on the
       // 128 x 256 tile at 256 x 256 pixels, profiles/r05_conv_bench_192_columns.txt)
-      static const Cand cands[] = {{24, 128, 192, 1, 4000, 16000}, {22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
+      // (27: 128 x 224 on four fragment sets, for outputs of exactly 224 stored columns -- the 196-channel layers in one column tile,
+      // 7 sub-tiles per SIMD and k-step instead of the 8 of 128 x 256)
+      static const Cand cands[] = {{24, 128, 192, 1, 4000, 16000}, {27, 128, 224, 1, 4250, 16000}, {22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
                                    {25, 128, 128, 1, 2600, 13000}, {26, 64, 128, 2, 1400, 11000},
                                    {2, 64, 64, 3, 1000, 9000}};
       const long long nk = g.K / 32, cus = 256;
       long long best = -1;
+      static const bool on224_env = getenv("OPP_TILE_224") && getenv("OPP_TILE_224")[0] == '1';       // A/B switch of the tools
 #ifdef OPP_TUNING
       static const int only_env = getenv("OPP_B3_ONLY_CFG") ? atoi(getenv("OPP_B3_ONLY_CFG")) : -1;   // tuning: force one tile
       static const int skip_env = getenv("OPP_B3_SKIP_BIG") ? atoi(getenv("OPP_B3_SKIP_BIG")) : 0;    // tuning: no 160 KB tiles
@@ -1284,6 +1377,12 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
 #endif
         if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
         if (c.bn == 192 && g.n_store % 192 != 0) continue;
+        // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles, 7 % faster than 128 x 256 on the one layer that
+        // runs two full rounds of it alone (l1_out2a: 292 vs 315 us), 9 % SLOWER per tile where the grid is half a round (131 vs 120 us at
+        // 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block, 15 ds_read_b128 per 24 MFMAs instead of 12), and the
+        // forward as a whole did not gain: 521 vs 526 images/s with four forwards in flight, 429.0 vs 429.2 with one, training step 53.9 vs
+        // 53.6 ms.  Not picked automatically; OPP_TILE_224=1 enables it for grids of at least one full round (tools, tests pass config 27).
+        if (c.bn == 224 && (g.n_store != 224 || !on224_env || opp_cdiv(g.M, 128) < 256)) continue;
         const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
         const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
         long long est = full * (nk * c.chunk * c.wpc + c.fixed);
@@ -1330,6 +1429,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
     case 24: rc = launch_cfg<128, 192, 4, 2>(g, stream); break;     // 8 waves, 32x96 per wave: 192-column bodies of the 196-channel layers
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
+    case 27: rc = g.prec == OPP_PREC_BF16X3 ? launch_cfg<128, 224, 4, 2>(g, stream) : OPP_ERR_UNSUPPORTED; break;   // 8 waves, 32 x 128 | 32 x 96 per wave, four fragment sets
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
     default:

@@ -323,7 +323,8 @@ def test_results_do_not_depend_on_the_tile_shape(h2):
         scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
         Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (Wd + 2 * (ks // 2) - ks) // stride + 1
         res = torch.randn(1, cout, Ho, Wo, generator=g)
-        outs = [ops.conv2d(x, w, scale, bias, stride, res, 1, 1, c, h2=h2)[0] for c in cfgs]
+        ccfgs = cfgs + ((27,) if (h2 == 3 and cout == 196) else ())      # 128 x 224 ring tile: the 196(->224)-column layers only
+        outs = [ops.conv2d(x, w, scale, bias, stride, res, 1, 1, c, h2=h2)[0] for c in ccfgs]
         assert all(torch.equal(outs[0], o) for o in outs[1:]), (cin, cout, ks, stride)
         if ks == 1 and stride == 1:      # FPN lateral: 1x1 conv + bilinear x2 residual
             low = torch.randn(1, cout, Ho // 2, Wo // 2, generator=g)

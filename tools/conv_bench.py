@@ -15,22 +15,24 @@ from onepose_plus_plus_amd import _lib  # noqa: E402
 
 # name, Hin, Win, cin, cout, ks, stride, cfgs
 CONVS = [
-    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 20, 25, 27, 106, 107, 101, 105, 102, 103]),
-    ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11, 20, 25, 27]),
+    ("layer1 3x3 128->128 @256", 256, 256, 128, 128, 3, 1, [0, 10, 11, 20, 25, 106, 107, 101, 105, 102, 103]),
+    ("l1_out2b 3x3 196->128 @256", 256, 256, 196, 128, 3, 1, [0, 10, 11, 20, 25]),
     ("l1_out2a 3x3 196->196 @256", 256, 256, 196, 196, 3, 1, [3, 11, 10, 0, 20, 22, 25, 27, 28]),
+    ("l1_outconv 1x1 128->196 @256", 256, 256, 128, 196, 1, 1, [22, 25, 27]),
+    # (27 = the 128 x 224 ring tile of the 196(->224)-column layers, bf16x3 only)
     # 196 = 192 + a 4-column tail: the 192-column part on the tuning library's 128 x 192 tile (config 140; run with
     # OPP_HIP_LIB=.../libopp_hip_tuning.so OPP_ABLATE=1, configs >= 100 are skipped otherwise)
     ("l1_out2a-192 3x3 196->192 @256", 256, 256, 196, 192, 3, 1, [140, 22, 25]),
     ("layer2-192 3x3 196->192 @128", 128, 128, 196, 192, 3, 1, [140, 25, 26]),
-    ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 1, 2, 0, 25, 26]),
-    ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [5, 1, 2, 0, 25, 26]),
-    ("l2_out2b 3x3 256->196 @128", 128, 128, 256, 196, 3, 1, [5, 1, 2, 0, 25, 26]),
+    ("layer2 3x3 196->196 @128", 128, 128, 196, 196, 3, 1, [5, 1, 2, 0, 22, 25, 26, 27]),
+    ("layer2.0 3x3s2 128->196 @256", 256, 256, 128, 196, 3, 2, [5, 1, 2, 0, 22, 25, 26, 27]),
+    ("l2_out2b 3x3 256->196 @128", 128, 128, 256, 196, 3, 1, [5, 1, 2, 0, 22, 25, 26, 27]),
     ("l2_out2a 3x3 256->256 @128", 128, 128, 256, 256, 3, 1, [1, 0, 2, 20, 22, 25, 26, 28]),
     ("layer3 3x3 256->256 @64", 64, 64, 256, 256, 3, 1, [2, 1, 26]),
 ]
 # name, M, K, N, cfgs
 DENSE = [
-    ("dense 65536x1152x128", 65536, 1152, 128, [0, 20, 25, 27]),
+    ("dense 65536x1152x128", 65536, 1152, 128, [0, 20, 25]),
     ("dense 65536x128x128", 65536, 128, 128, [0]),
     ("qkv 9096x256x768", 9096, 256, 768, [0, 1, 20, 22, 25, 28]),
     ("merge 9096x256x256", 9096, 256, 256, [1, 2, 0, 25, 26]),
@@ -62,11 +64,11 @@ def split_w(lib, w, cfgs, prec, s):
     if prec == 1:
         w2 = torch.empty_like(w)
         _lib.check(lib.opp_pack_h2(w.data_ptr(), w2.data_ptr(), w.numel(), None, s), "pack_h2")
-        return w2, sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 27, 28, 30)] + [-1]))
+        return w2, sorted(set([c for c in cfgs if c in (0, 1, 2, 10, 11, 20, 22, 25, 26, 28, 30)] + [-1]))
     if prec == 2:
         w2 = torch.empty(w.numel() // 2 * 3, device="cuda")
         _lib.check(lib.opp_pack_b3(w.data_ptr(), w2.data_ptr(), w.numel(), s), "pack_b3")
-        ok = (0, 1, 2, 10, 20, 22, 25, 26, 30) + ((140,) if os.environ.get("OPP_ABLATE") else ())     # 140: the tuning library's 128 x 192 tile
+        ok = (0, 1, 2, 10, 20, 22, 25, 26, 27, 30) + ((140,) if os.environ.get("OPP_ABLATE") else ())     # 140: the tuning library's 128 x 192 tile
         return w2, sorted(set([c for c in cfgs if c in ok] + [-1]))
     return w, cfgs
 
