@@ -59,6 +59,7 @@ PREC_ID = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 1, "bf16x3": 2}
 GEMM_SYMBOLS = [
     (20, 1, "256, 128, 4, 2, true", "implicit-GEMM conv, 256x128 tile, 8 waves"),
     (22, 1, "128, 256, 2, 4, true", "implicit-GEMM conv, 128x256 tile, 8 waves"),
+    (27, 1, "128, 224, 4, 2, true", "implicit-GEMM conv, 128x224 tile on four fragment sets, 8 waves: the 196(->224)-column layers on grids of >= one full round (latency tile policy)"),
     (24, 1, "128, 192, 4, 2, true", "implicit-GEMM conv, 128x192 tile, 8 waves: the 192-column body of the 196-channel layers (last 4 columns: conv_tail_kernel)"),
     (25, 1, "128, 128, 4, 2, true", "implicit-GEMM conv, 128x128 tile, 8 waves"),
     (26, 1, "64, 128, 2, 4, true", "implicit-GEMM conv, 64x128 tile, 8 waves"),

@@ -645,6 +645,7 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   g.C = y;
   g.ldc = d.cout_pad();
   g.n_store = d.cout_pad();
+  g.n_real = d.cout;
   g.bias = raw ? nullptr : d.bias;
   g.res_mode = res_mode;
   g.R = res;
@@ -1124,6 +1125,7 @@ int conv_backward(const float* x, int B, int Hin, int Win, int cin, const float*
     g.C = dx;
     g.ldc = cin_pad;
     g.n_store = cin_pad;
+    g.n_real = cin;
     if (dx_add) {
       g.res_mode = OPP_RES_DIRECT;
       g.R = dx_add;

@@ -58,10 +58,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   constexpr int TN = (NT32 + WAVES_N - 1) / WAVES_N;          // per wave (last wave may own fewer)
   constexpr bool kRagged = (NT32 % WAVES_N) != 0;             // e.g. 224 columns on 2 waves = 4 + 3
   constexpr int A_LD = BM * 8 / NT;
-  constexpr int B_LD = H3 ? (BN * 12 + NT - 1) / NT : BN * 8 / NT;   // bf16x3 weights: 192 B per row and chunk
+  // 224-column ring tile: weight rows >= 208 are never real (the tile serves N <= 208, i.e. the 196-channel layers; the launcher checks) --
+  // their LDS rows are zeroed once and the loader covers 208 rows = 4.9 pieces per thread instead of 5.25 (one prefetch register set less)
+  constexpr int kBRowsLoad = (H3 && BN == 224) ? 208 : BN;
+  constexpr int B_LD = H3 ? (kBRowsLoad * 12 + NT - 1) / NT : BN * 8 / NT;   // bf16x3 weights: 192 B per row and chunk
   // a 192-column tile (tuning builds: 196 = 192 + a tail) has 4.5 weight pieces per thread: the upper half of the workgroup loads zeros
   // for its fifth piece and does not store it
-  constexpr bool kBFrac = H3 && (BN * 12) % NT != 0;
+  constexpr bool kBFrac = H3 && (kBRowsLoad * 12) % NT != 0;
   // 224-column tile (r05: the 196(->224)-channel layers in ONE column tile, 7 sub-tiles of 32 columns on 2 x 4 waves): the waves with
   // wn = 0 own 4 sub-tiles, those with wn = 1 own 3, and the wave -> (wm, wn) map puts one of each on every SIMD (waves w and w + 4 share
   // SIMD w % 4), so every matrix pipe runs 7 sub-tiles per k-step where the 128 x 256 tile runs 8.  The 32 x 128 wave tile only fits the
@@ -142,15 +145,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       a_mask[i] = 0;
     }
   }
-  unsigned b_base[B_LD];
-  int b_lds[B_LD];   // LDS float offset of the slot inside the B tile
+  constexpr bool kRingB = H3 && (NT32 % WAVES_N) != 0;   // (= kRing) the ring tile recomputes these per use: 12 registers it does not have
+  unsigned b_base[kRingB ? 1 : B_LD];
+  int b_lds[kRingB ? 1 : B_LD];   // LDS float offset of the slot inside the B tile
+  auto ring_b = [&](int i, unsigned& base, int& lds) {
+    int t = tid;
+    asm volatile("" : "+v"(t));                          // recompute at every use: hoisted out of the loops these are 12 live registers
+    const int u = t + i * NT;
+    const int row = u / 12, c = u - row * 12;
+    const int n = n0 + row;
+    base = (n < g.N && u < kBRowsLoad * 12) ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
+    lds = row * kLdsStride + c * 4;
+  };
 #pragma unroll
-  for (int i = 0; i < B_LD; ++i) {
+  for (int i = 0; i < (kRingB ? 0 : B_LD); ++i) {
     if (H3) {   // pre-split weights: a row's chunk is 12 x 16 B ([hi x8 | mid x8 | lo x8] per 8 k)
       const int u = tid + i * NT;
       const int row = u / 12, c = u - row * 12;
       const int n = n0 + row;
-      if constexpr (kBFrac) b_base[i] = (n < g.N && u < BN * 12) ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
+      if constexpr (kBFrac) b_base[i] = (n < g.N && u < kBRowsLoad * 12) ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
       else b_base[i] = n < g.N ? (unsigned)(n * g.ldw + c * 4) * 4u : kOob;
       b_lds[i] = row * kLdsStride + c * 4;
     } else {
@@ -265,7 +278,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       }
     } else {
       const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, live ? g.w_bytes : 0, 0x00020000);
-      b_reg[i - A_LD] = bload(r, b_base[i - A_LD] + (unsigned)cur_k0 * (H3 ? 6u : 4u));
+      if constexpr (kRingB) {
+        unsigned base;
+        int lds;
+        ring_b(i - A_LD, base, lds);
+        b_reg[i - A_LD] = bload(r, base + (unsigned)cur_k0 * 6u);
+      } else {
+        b_reg[i - A_LD] = bload(r, b_base[i - A_LD] + (unsigned)cur_k0 * (H3 ? 6u : 4u));
+      }
     }
   };
   auto load_global = [&](float4 (&a_reg)[A_LD], float4 (&b_reg)[B_LD]) {
@@ -333,8 +353,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         *reinterpret_cast<float4*>(row + kq * 4) = a_reg[i];
       }
     } else {
-      if constexpr (kBFrac) {
-        if (tid + (i - A_LD) * NT < BN * 12) *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
+      if constexpr (kRingB) {
+        unsigned base;
+        int lds;
+        ring_b(i - A_LD, base, lds);
+        if (tid + (i - A_LD) * NT < kBRowsLoad * 12) *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + lds) = b_reg[i - A_LD];
+      } else if constexpr (kBFrac) {
+        if (tid + (i - A_LD) * NT < kBRowsLoad * 12) *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
       } else {
         *reinterpret_cast<float4*>(Bs + buf * BN * kLdsStride + b_lds[i - A_LD]) = b_reg[i - A_LD];
       }
@@ -416,12 +441,27 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   float4 fa[(H3 && !kRing) ? 6 : 4][TM], fb[(H3 && !kRing) ? 6 : 4][TN];
   float4 da[A_LD], db[B_LD];   // ablation 5 only: load sink that is never consumed in the loop
 
+  if constexpr (kRing) {
+    load_global(ga[0], gb[0]);                         // chunk 0 (its weight rows go to LDS below, ahead of the reload of the single set)
+  } else {
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) {
-    if (d) advance();
-    load_global(ga[d], gb[d]);
+    for (int d = 0; d < DEPTH; ++d) {
+      if (d) advance();
+      load_global(ga[d], gb[d]);
+    }
+  }
+  if constexpr (kBRowsLoad < BN) {   // weight rows the loader never touches: zero in both buffers
+    for (int u = tid; u < 2 * (BN - kBRowsLoad) * kLdsStride; u += NT) {
+      const int b = u / ((BN - kBRowsLoad) * kLdsStride), o = u - b * ((BN - kBRowsLoad) * kLdsStride);
+      Bs[b * BN * kLdsStride + kBRowsLoad * kLdsStride + o] = 0.f;
+    }
   }
   store_lds(0, ga[0], gb[0]);
+  if constexpr (kRing) {
+    __builtin_amdgcn_sched_barrier(0);
+    advance();
+    load_global(ga[1], gb[0]);                         // chunk 1: activations into set 1, weights into the single set
+  }
   __syncthreads();
   read_frags(0, 0, fa[0], fb[0]);
   if constexpr (kRing) {
@@ -628,7 +668,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   //   step 0:  read hi1 | P0 P1 | read lo1 | P2 P3 P4 | read mid1 | P5          (+ the global prefetch of chunk c+2, one load per slot)
   //   step 1:  P0 P1 P2 (+ the LDS hand-over of chunk c+1) | barrier | read hi0' lo0' of chunk c+1 | P3 P4 | read mid0' | P5
   // Every read is issued >= 12 MFMAs ahead of its first use; the barrier sits under the last three products as in chunk_h3.
-  auto mfma_ring = [&](int hs, int p0, int p1, int n0, auto&& between) {
+  // The number of live column sub-tiles of the wave (4 for wn = 0, 3 for wn = 1) is a COMPILE-TIME parameter of the loop body: the K loop exists
+  // twice and the wave picks its copy once, ahead of the loop.  (First version: one body with the wave-uniform `tile_ok[j]` test around every
+  // MFMA and fragment read -- 3 x the scalar instructions and 7 x the s_nop / branch class of the 128 x 256 kernel in the counters,
+  // profiles/r05_pmc_conv_224_vs_256.txt, and 14 % more wave cycles for 12.5 % fewer MFMAs.)
+  auto read_frags_n = [&](int buf, int q, float4 (&af)[TM], float4 (&bf)[TN], auto tnw_c) {
+    constexpr int TNW = decltype(tnw_c)::value;
+    const int qoff = (q / 3) * 24 + (q % 3) * 4;
+    const float* as = As + buf * BM * kLdsStride + a_frag + qoff;
+    const float* bs = Bs + buf * BN * kLdsStride + b_frag + qoff;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * kLdsStride);
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) bf[j] = *reinterpret_cast<const float4*>(bs + j * 32 * kLdsStride);
+  };
+  auto mfma_ring = [&](int hs, int p0, int p1, int n0, auto tnw_c, auto&& between) {
+    constexpr int TNW = decltype(tnw_c)::value;
     int n = n0;
 #pragma unroll
     for (int pr = 0; pr < 6; ++pr) {
@@ -639,60 +694,74 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (tile_ok[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[sa & 3][i]), as_b8(fb[sb & 3][j]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TNW; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(fa[sa & 3][i]), as_b8(fb[sb & 3][j]), acc[i][j], 0, 0, 0);
           between(n);
           ++n;
         }
     }
   };
-  constexpr int kSlotsR0 = 6 * TM * TN;                   // step 0: all six products carry the prefetch
-  constexpr int kStrideR0 = kSlotsR0 / kItems > 0 ? kSlotsR0 / kItems : 1;
-  constexpr int kSlotsR1 = 3 * TM * TN;                   // step 1: the first three carry the LDS hand-over
-  constexpr int kStrideR1 = kSlotsR1 / kItems > 0 ? kSlotsR1 / kItems : 1;
-  auto chunk_ring = [&](auto set, int lb) {
+  // Global prefetch of the ring tile: the activation rows of chunk c+2 are loaded during step 0 of chunk c (two register sets, as everywhere);
+  // the WEIGHT rows -- L2-resident, a few hundred cycles away -- have ONE register set: loaded under the last three products of chunk c
+  // (right after the barrier behind which the set's previous content went to LDS), handed to LDS under the first three products of step 1 of
+  // chunk c+1, a whole k16-step later.  20 registers less than two sets; the 32 x 128 wave tile does not fit without them.
+  auto chunk_ring = [&](auto set, int lb, auto tnw_c) {
     constexpr int P = decltype(set)::value;
     constexpr int PN = (P + 1) % DEPTH;
+    constexpr int TNW = decltype(tnw_c)::value;
+    constexpr int kSlotsR0 = 6 * TM * TNW;                  // step 0: all six products carry the activation prefetch
+    constexpr int kStrideR0 = kSlotsR0 / A_LD > 0 ? kSlotsR0 / A_LD : 1;
+    constexpr int kSlotsR1 = 3 * TM * TNW;                  // step 1: the first three carry the LDS hand-over, the last three the weight prefetch
+    constexpr int kStrideR1 = kSlotsR1 / kItems > 0 ? kSlotsR1 / kItems : 1;
+    constexpr int kStrideRB = kSlotsR1 / B_LD > 0 ? kSlotsR1 / B_LD : 1;
     const int B0 = lb, B1 = lb ^ 1;
     auto pre = [&](int n) {
-      if (n % kStrideR0 == 0 && n / kStrideR0 < kItems) {
-        load_item(n / kStrideR0, ga[P], gb[P]);
+      if (n % kStrideR0 == 0 && n / kStrideR0 < A_LD) {
+        load_item(n / kStrideR0, ga[P], gb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto pre_b = [&](int n) {
+      if (n % kStrideRB == 0 && n / kStrideRB < B_LD) {
+        load_item(A_LD + n / kStrideRB, ga[P], gb[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
     advance();
-    read_frags(B0, 3, fa[1], fb[1]);                  // hi of step 1
+    read_frags_n(B0, 3, fa[1], fb[1], tnw_c);         // hi of step 1
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(0, 0, 2, 0, pre);
+    mfma_ring(0, 0, 2, 0, tnw_c, pre);
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(B0, 5, fa[3], fb[3]);                  // lo of step 1 over the (dead) lo of step 0
+    read_frags_n(B0, 5, fa[3], fb[3], tnw_c);         // lo of step 1 over the (dead) lo of step 0
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(0, 2, 5, 2 * TM * TN, pre);
+    mfma_ring(0, 2, 5, 2 * TM * TNW, tnw_c, pre);
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(B0, 4, fa[2], fb[2]);                  // mid of step 1 over the (dead) mid of step 0
+    read_frags_n(B0, 4, fa[2], fb[2], tnw_c);         // mid of step 1 over the (dead) mid of step 0
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(0, 5, 6, 5 * TM * TN, pre);
+    mfma_ring(0, 5, 6, 5 * TM * TNW, tnw_c, pre);
 #pragma unroll
-    for (int i = kSlotsR0 / kStrideR0; i < kItems; ++i) load_item(i, ga[P], gb[P]);
+    for (int i = kSlotsR0 / kStrideR0; i < A_LD; ++i) load_item(i, ga[P], gb[0]);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(1, 0, 3, 0, [&](int n) {                // step 1, first three products + LDS hand-over of chunk c+1
+    mfma_ring(1, 0, 3, 0, tnw_c, [&](int n) {         // step 1, first three products + LDS hand-over of chunk c+1
       if (n % kStrideR1 == 0 && n / kStrideR1 < kItems) {
-        store_item(n / kStrideR1, B1, ga[PN], gb[PN]);
+        store_item(n / kStrideR1, B1, ga[PN], gb[0]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
-    for (int i = kSlotsR1 / kStrideR1; i < kItems; ++i) store_item(i, B1, ga[PN], gb[PN]);
+    for (int i = kSlotsR1 / kStrideR1; i < kItems; ++i) store_item(i, B1, ga[PN], gb[0]);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    read_frags(B1, 0, fa[0], fb[0]);                  // chunk c+1: hi of step 0 (set 0 is dead since step 0's last product)
-    read_frags(B1, 2, fa[3], fb[3]);                  //            lo of step 0 (lo of step 1 is dead after its second product)
+    read_frags_n(B1, 0, fa[0], fb[0], tnw_c);         // chunk c+1: hi of step 0 (set 0 is dead since step 0's last product)
+    read_frags_n(B1, 2, fa[3], fb[3], tnw_c);         //            lo of step 0 (lo of step 1 is dead after its second product)
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(1, 3, 5, 0, nothing);
+    mfma_ring(1, 3, 5, 0, tnw_c, pre_b);              // + the weight rows of chunk c+2 into the (just stored) single set
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(B1, 1, fa[2], fb[2]);                  //            mid of step 0 over the (dead) mid of step 1
+    read_frags_n(B1, 1, fa[2], fb[2], tnw_c);         //            mid of step 0 over the (dead) mid of step 1
     __builtin_amdgcn_sched_barrier(0);
-    mfma_ring(1, 5, 6, 0, nothing);
+    mfma_ring(1, 5, 6, 2 * TM * TNW, tnw_c, pre_b);
+#pragma unroll
+    for (int i = kSlotsR1 / kStrideRB; i < B_LD; ++i) load_item(A_LD + i, ga[P], gb[0]);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -701,11 +770,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // static s_setprio for that half evens the pair out (MI355X_MICROARCH.md, "two waves per SIMD", item 4).  The guard must be
   // provably wave-uniform: s_setprio ignores EXEC.
   if (NT == 512 && (g.xcd_swizzle & 2) && __builtin_amdgcn_readfirstlane(tid) >= 256) __builtin_amdgcn_s_setprio(1);
+  if constexpr (kRing) {
+    constexpr int kFull = TN, kShort = NT32 - (WAVES_N - 1) * TN;     // live sub-tiles of the waves with wn < WAVES_N - 1 / of the last ones
+    static_assert(DEPTH == 2 && kShort >= 1 && kShort <= TN, "ring tile");
+    if (wn != WAVES_N - 1) {                                           // wave-uniform; both loops cross the same barriers
+      for (int c = 0; c < nk; c += 2) {
+        chunk_ring(std::integral_constant<int, 0>{}, c & 1, std::integral_constant<int, kFull>{});
+        chunk_ring(std::integral_constant<int, 1>{}, (c + 1) & 1, std::integral_constant<int, kFull>{});
+      }
+    } else {
+      for (int c = 0; c < nk; c += 2) {
+        chunk_ring(std::integral_constant<int, 0>{}, c & 1, std::integral_constant<int, kShort>{});
+        chunk_ring(std::integral_constant<int, 1>{}, (c + 1) & 1, std::integral_constant<int, kShort>{});
+      }
+    }
+  }
   // nk rounded up to a multiple of DEPTH: the extra chunks are all-zero ones
-  for (int c = 0; c < nk; c += DEPTH) {
+  for (int c = 0; c < (kRing ? 0 : nk); c += DEPTH) {
     if constexpr (kRing) {
-      chunk_ring(std::integral_constant<int, 0>{}, c & 1);
-      if (DEPTH > 1) chunk_ring(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
+      // (handled by the two loops above)
     } else if constexpr (H3) {
       chunk_h3(std::integral_constant<int, 0>{}, c & 1);
       if (DEPTH > 1) chunk_h3(std::integral_constant<int, 1 % DEPTH>{}, (c + 1) & 1);
@@ -1365,7 +1448,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
                                    {2, 64, 64, 3, 1000, 9000}};
       const long long nk = g.K / 32, cus = 256;
       long long best = -1;
-      static const bool on224_env = getenv("OPP_TILE_224") && getenv("OPP_TILE_224")[0] == '1';       // A/B switch of the tools
+      static const int on224_env = getenv("OPP_TILE_224") ? atoi(getenv("OPP_TILE_224")) : 1;         // A/B switch of the tools
 #ifdef OPP_TUNING
       static const int only_env = getenv("OPP_B3_ONLY_CFG") ? atoi(getenv("OPP_B3_ONLY_CFG")) : -1;   // tuning: force one tile
       static const int skip_env = getenv("OPP_B3_SKIP_BIG") ? atoi(getenv("OPP_B3_SKIP_BIG")) : 0;    // tuning: no 160 KB tiles
@@ -1377,12 +1460,14 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
 #endif
         if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
         if (c.bn == 192 && g.n_store % 192 != 0) continue;
-        // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles, 7 % faster than 128 x 256 on the one layer that
-        // runs two full rounds of it alone (l1_out2a: 292 vs 315 us), 9 % SLOWER per tile where the grid is half a round (131 vs 120 us at
-        // 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block, 15 ds_read_b128 per 24 MFMAs instead of 12), and the
-        // forward as a whole did not gain: 521 vs 526 images/s with four forwards in flight, 429.0 vs 429.2 with one, training step 53.9 vs
-        // 53.6 ms.  Not picked automatically; OPP_TILE_224=1 enables it for grids of at least one full round (tools, tests pass config 27).
-        if (c.bn == 224 && (g.n_store != 224 || !on224_env || opp_cdiv(g.M, 128) < 256)) continue;
+        // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles; 10 % faster than 128 x 256 on a grid of two full
+        // rounds (l1_out2a: 283 vs 315 us; one forward in flight +1.4 ... 2.8 % images/s), 5-8 % SLOWER per tile where the grid is half a round
+        // (125 vs 118 us at 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block), and with several forwards in flight
+        // it LOSES 1-2 % even on the big grid -- the chip is power-limited there, the eighth sub-tile of 128 x 256 multiplies zeros (cheap in
+        // energy, only costly in time) while the ring tile moves 25 % more fragment bytes per useful MFMA.  So: latency policy, grids of at
+        // least one full round (OPP_TILE_224=0 never, =2 always: the A/B switch of the tools).
+        if (c.bn == 224 && (g.n_store != 224 || g.n_real <= 0 || g.n_real > 208 || on224_env == 0 ||
+                            (on224_env != 2 && (g.tile_policy == OPP_TILES_THROUGHPUT || opp_cdiv(g.M, 128) < 256)))) continue;
         const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
         const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
         long long est = full * (nk * c.chunk * c.wpc + c.fixed);
@@ -1429,7 +1514,15 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     case 22: rc = launch_cfg<128, 256, 2, 4>(g, stream); break;
     case 24: rc = launch_cfg<128, 192, 4, 2>(g, stream); break;     // 8 waves, 32x96 per wave: 192-column bodies of the 196-channel layers
     case 25: rc = launch_cfg<128, 128, 4, 2>(g, stream); break;     // 8 waves, 32x64 per wave (M ~ 16k layers)
-    case 27: rc = g.prec == OPP_PREC_BF16X3 ? launch_cfg<128, 224, 4, 2>(g, stream) : OPP_ERR_UNSUPPORTED; break;   // 8 waves, 32 x 128 | 32 x 96 per wave, four fragment sets
+    case 27:
+      // (explicit requests -- tests, tools -- vouch for zero weight rows >= 208 themselves: the C ABI of the single convolution carries the padded count only)
+      if (g.prec != OPP_PREC_BF16X3 || g.n_store > 224 || (g.n_real > 208 && g.n_real != g.n_store)) {
+        opp_set_error("gemm: tile config 27 (128 x 224) is a bf16x3 tile for outputs of <= 208 real and <= 224 stored columns");
+        rc = OPP_ERR_UNSUPPORTED;
+      } else {
+        rc = launch_cfg<128, 224, 4, 2>(g, stream);
+      }
+      break;   // 8 waves, 32 x 128 | 32 x 96 per wave, four fragment sets
     case 26: rc = launch_cfg<64, 128, 2, 4>(g, stream); break;      // 8 waves, 32x32 per wave
     case 30: rc = launch_cfg<64, 256, 2, 4>(g, stream); break;      // 8 waves, full 256-column rows (fused LayerNorm)
     default:

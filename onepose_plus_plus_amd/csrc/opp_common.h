@@ -99,6 +99,7 @@ struct OppGemm {
   float* C = nullptr;
   int ldc = 0;
   int n_store = 0;  // columns [0, n_store) are written (n_store >= N pads with act(0))
+  int n_real = 0;   // > 0: weight rows >= n_real are known to be zero padding (channel counts padded to 32); lets the 128 x 224 tile skip rows >= 208
   const float* bias = nullptr;  // [n_store] or null
   // residual added before the activation
   int res_mode = OPP_RES_NONE;

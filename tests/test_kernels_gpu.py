@@ -56,7 +56,7 @@ def test_linear_bf16x3(M, K, N, cfg):
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
     assert (err <= 1e-6 * _bound(A, W) + 1e-6).all(), float(err.max())
-    for bad in (27, 28, 3):      # tiles without a bf16x3 build are refused, never silently another arithmetic
+    for bad in (28, 29, 3):      # tiles without a bf16x3 build are refused, never silently another arithmetic
         with pytest.raises(Exception):
             ops.linear(A, W, 0, bad, h2=3)
 
@@ -313,9 +313,10 @@ def test_results_do_not_depend_on_the_tile_shape(h2):
     from tests import hip_ops as ops
     g = torch.Generator().manual_seed(1)
     cfgs = (25, 26, 22, 20, 2) if h2 != 0 else (25, 26, 20, 22, 2, 1, 0)
-    for (M, K, N) in [(1000, 512, 512), (156, 128, 384), (4096, 64, 128)]:
+    for (M, K, N) in [(1000, 512, 512), (156, 128, 384), (4096, 64, 128), (700, 256, 196)]:
         A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
-        outs = [ops.linear(A, W, 1, c, h2=h2) for c in cfgs]
+        dcfgs = cfgs + ((27,) if (h2 == 3 and N <= 208) else ())          # 128 x 224 ring tile: <= 208 real columns
+        outs = [ops.linear(A, W, 1, c, h2=h2) for c in dcfgs]
         assert all(torch.equal(outs[0], o) for o in outs[1:]), (M, K, N)
     for (cin, cout, ks, stride, H, Wd) in [(128, 128, 3, 1, 64, 64), (128, 196, 3, 2, 64, 64), (196, 196, 3, 1, 32, 48), (196, 256, 1, 1, 16, 24)]:
         x = torch.randn(1, cin, H, Wd, generator=g)
