@@ -19,7 +19,10 @@ from onepose_plus_plus_amd import build  # noqa: E402
 
 # kernels known to use scratch: the PnP solvers keep per-thread 3x4 / 6x6 systems in indexed local arrays (304-400 B), the focal-loss
 # forward indexes a 6-float weight struct (24 B) -- none of them is on the matching forward's path
-ALLOW_SCRATCH = ("pnp_", "focal_fwd_kernel")
+# the 128 x 224 ring tile (gemm_mfma.hip, config 27) sits at the 256-register limit of a two-waves-per-SIMD kernel: 104-124 B of spills, all of them
+# outside the K loops except the division constant of the K-tail cursor (2 dword reloads per chunk) -- located with the MFMA index of every
+# scratch instruction when the tile was written
+ALLOW_SCRATCH = ("pnp_", "focal_fwd_kernel", "opp_gemm_kernelILi128ELi224E")
 
 
 def audit_source(src, tuning, tmp):
