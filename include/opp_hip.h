@@ -404,7 +404,8 @@ int opp_build_assignmatrix(const float* kp2d_coarse, const float* kp2d_fine, int
  * ks*ks*cin_pad, or the shorter K-tail packing for a 3x3 kernel over 32 n + (1..4) channels); bias [cout_pad] or NULL; residual:
  * res_mode 0 none, 1 same-shape NHWC [Hout][Wout][cout_pad], 2 bilinear x2 (align_corners)
  * upsample of NHWC [Hout/2][Wout/2][cout_pad]; act 0 none, 1 ReLU, 2 LeakyReLU(0.01).
- * tile_cfg < 0 selects automatically.  prec = operand arithmetic: 0 fp32; 1 fp16x2 (w_packed additionally
+ * tile_cfg < 0 selects automatically (an explicit 27 -- the 128x224 tile -- treats weight rows >= 208 as the zero padding they are for a
+ * 196-channel layer: the caller vouches for it).  prec = operand arithmetic: 0 fp32; 1 fp16x2 (w_packed additionally
  * pre-split by opp_pack_h2, h2_scale = the scale2 pointer given to it, or NULL); 2 bf16x3 (w_packed pre-split by
  * opp_pack_b3, 1.5x the floats). */
 int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin, const float* w_packed,
@@ -481,7 +482,8 @@ int opp_debug_timestamps(void* buf);
 /* ---- live kernel timing for bench.py's roofline leg ---------------------------------------
  * Arms HIP-event timing (events recorded on the launch stream) of every launch of ONE kernel symbol:
  *   tile_cfg < 1000: a GEMM tile configuration (0 128x128/4 waves, 1 64x128, 2 64x64, 10/11 deeper prefetch,
- *                    20 256x128/8 waves, 22 128x256/8 waves, 25 128x128/8 waves, 26 64x128/8 waves, 30 64x256/8 waves + fused LayerNorm) of
+ *                    20 256x128/8 waves, 22 128x256/8 waves, 24 128x192/8 waves, 25 128x128/8 waves, 26 64x128/8 waves,
+ *                    27 128x224/8 waves on four fragment sets (bf16x3; outputs of <= 208 real / <= 224 stored columns), 30 64x256/8 waves + fused LayerNorm) of
  *                    kind 0 dense GEMM, 1 implicit-GEMM conv, 2 coarse score GEMM with fused softmax statistics;
  *   tile_cfg 1000 linear-attention KV gather, 1001 linear-attention apply, 1002 dual-softmax confidence pass,
  *            1003 the whole fine stage, 1004 fine-level attention (one workgroup per match), 1005 window gather,
