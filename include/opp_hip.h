@@ -425,6 +425,13 @@ int opp_conv_packed_k(int cin, int ks);
 size_t opp_linear_attention_workspace_bytes(int n_seg, int len0, int len1, int C, int nhead);
 int opp_linear_attention(const float* qkv, int n_seg, int len0, int len1, int C, int nhead, int cross,
                          float* msg, void* workspace, size_t workspace_bytes, void* stream);
+/* The tile configuration the GEMM / implicit-GEMM convolution launcher picks by itself (tile_cfg < 0) for an M x n_store output over K (a multiple
+ * of 32) -- a pure host function of shape, operand arithmetic (prec as in opp_conv2d_nhwc) and tile policy (0 latency, 1 throughput: opp_config.tile_policy),
+ * exported so that the policy is testable without a device.  n_real = real output channels when n_store is their padded count (0 = unknown), conv != 0
+ * for a convolution.  Returns the tile config (the list under opp_profile_start), + 1000 when a bf16x3 convolution of this shape runs as four K slices
+ * on that tile, or a negative OPP_ERR_*.  Replaces nothing in the reference (cuDNN / cuBLAS pick their own kernels: backbone/resnet.py:10-45). */
+int opp_gemm_tile_for(int M, int n_real, int n_store, int K, int conv, int prec, int tile_policy);
+
 /* C[M][N] = act(A[M][K] * W[N][K]^T) ; act 0 none, 1 ReLU.  prec as above (1: W pre-split by opp_pack_h2,
  * 2: by opp_pack_b3). */
 int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C,

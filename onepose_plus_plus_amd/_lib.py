@@ -121,6 +121,7 @@ SIGNATURES = {
     "opp_linear_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "opp_linear_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "opp_gemm_tile_for": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "opp_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "opp_linear_layernorm": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_void_p]),

@@ -2218,6 +2218,24 @@ extern "C" int opp_pack_b3(const float* in, float* out, size_t n, void* stream) 
   return opp_b3_split(in, out, n, (hipStream_t)stream);
 }
 
+extern "C" int opp_gemm_tile_for(int M, int n_real, int n_store, int K, int conv, int prec, int tile_policy) {
+  if (M <= 0 || n_store <= 0 || K <= 0 || K % 32 != 0 || prec < OPP_PREC_FP32 || prec > OPP_PREC_BF16X3 ||
+      (tile_policy != OPP_TILES_LATENCY && tile_policy != OPP_TILES_THROUGHPUT)) {
+    opp_set_error("gemm_tile_for: bad shape / arithmetic / policy");
+    return OPP_ERR_INVALID;
+  }
+  OppGemm g;
+  g.M = M;
+  g.N = n_store;
+  g.n_store = n_store;
+  g.n_real = n_real;
+  g.K = K;
+  g.conv = conv != 0;
+  g.prec = prec;
+  g.tile_policy = tile_policy;
+  return opp_gemm_choose_tile(g);
+}
+
 extern "C" int opp_linear(const float* A, int M, int K, const float* W, int N, int act, float* C, int tile_cfg, int prec,
                           const float* h2_scale, void* stream) {
   OPP_CHECK_ARG(prec >= OPP_PREC_FP32 && prec <= OPP_PREC_BF16X3, "linear: prec must be 0 (fp32), 1 (fp16x2) or 2 (bf16x3)");

@@ -1322,6 +1322,101 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
 
 }  // namespace
 
+// few output tiles under a long K: the convolution runs as 4 K slices (shape-only, identical under both tile policies)
+static bool splitk_by_shape(const OppGemm& g) {
+  const long long tiles128 = (long long)opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
+  return tiles128 <= 64 && g.K / 32 >= 32;
+}
+
+// The launcher's own tile choice (tile_cfg < 0) as a pure function of the problem shape, the operand arithmetic and the tile policy:
+// no device, no launch -- opp_gemm_tile_for (api.hip) exports it so that the policy is pinned by CPU tests (tests/test_host_logic.py).
+static int choose_tile(const OppGemm& g) {
+  const bool split = g.prec != OPP_PREC_FP32;
+  int cfg = -1;
+  // Tile choice from the MI355X micro-bench (tools/conv_bench.py; 256 CUs x 4 SIMDs).  The
+  // 196(->224)-channel stages run as two column tiles (128 + 96 real columns): measured 4-12 %
+  // faster than dedicated 128x224 / 64x224 tiles (removed).
+  const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
+  const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
+  if (t0 >= 384) cfg = 0;
+  else if (t1 >= 512) cfg = 1;
+  else cfg = 2;
+  // prefetch depth of the long-K convolutions on 128x128 tiles: 4 register sets when the grid
+  // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
+  // (split operands: the MFMA phase is shorter, depth 2 measured best on every layer)
+  if (g.conv && g.K >= 768 && cfg == 0 && !split) cfg = t0 <= 512 ? 11 : 10;
+  // fp32, 128-column outputs of the 256x256-pixel layers: the 8-wave 128x128 tile (two waves per SIMD cover the
+  // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
+  if (!split && t0 >= 384 && g.n_store <= 128) cfg = 25;
+  if (g.prec == OPP_PREC_FP16X2) {
+    // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Policy:
+    // 128x128 (73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel --
+    // fits on the CU) wherever it still gives ~a workgroup per CU, else 64x128, else the 4-wave 64x64 tile.
+    // The 256x128 / 128x256 tiles (110 KB LDS) are 2-5 % faster for a kernel running alone on the two
+    // largest layers but cost 2.3 % of the throughput with three forwards in flight (no co-residency).
+    if (t0 >= 200) cfg = 25;          // 128x128 on 8 waves (32x64 per wave)
+    else if (t1 >= 512) cfg = 26;     // 64x128 on 8 waves
+    else cfg = 2;
+  } else if (g.prec == OPP_PREC_BF16X3) {
+    // bf16x3: the operand tiles are 1.5x larger (208 B per row and chunk), so the 128x128 tile already owns a CU
+    // (106 KB LDS) and the grid runs in whole rounds of <= 256 workgroups: pick the tile with the smallest
+    // estimated time = rounds x (K chunks x cycles per chunk + prologue / epilogue), constants from the MI355X
+    // micro-bench (tools/conv_bench.py --prec 2): the 256x128 / 128x256 8-wave tiles (160 KB LDS, 64x64 per wave)
+    // win wherever they still fill the chip in one round (256x256-pixel layers, QKV), 128x128 on the 128x128-pixel
+    // layers, 64x128 (80 KB, two workgroups per CU) / 64x64 below that.
+    // wpc = workgroups of this tile that share a CU (by LDS); co-resident workgroups share the matrix pipes, so a
+    // chunk then costs wpc x the stand-alone time.
+    struct Cand { int cfg, bm, bn, wpc, chunk, fixed; };
+    // (24: 128 x 192, for outputs that are whole 192-column tiles -- the body of a 196-channel layer: measured 228 us against 272 on the
+    // 128 x 256 tile at 256 x 256 pixels, profiles/r05_conv_bench_192_columns.txt)
+    // (27: 128 x 224 on four fragment sets, for outputs of exactly 224 stored columns -- the 196-channel layers in one column tile,
+    // 7 sub-tiles per SIMD and k-step instead of the 8 of 128 x 256)
+    static const Cand cands[] = {{24, 128, 192, 1, 4000, 16000}, {27, 128, 224, 1, 4250, 16000}, {22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
+                                 {25, 128, 128, 1, 2600, 13000}, {26, 64, 128, 2, 1400, 11000},
+                                 {2, 64, 64, 3, 1000, 9000}};
+    const long long nk = g.K / 32, cus = 256;
+    long long best = -1;
+    static const int on224_env = getenv("OPP_TILE_224") ? atoi(getenv("OPP_TILE_224")) : 1;         // A/B switch of the tools
+#ifdef OPP_TUNING
+    static const int only_env = getenv("OPP_B3_ONLY_CFG") ? atoi(getenv("OPP_B3_ONLY_CFG")) : -1;   // tuning: force one tile
+    static const int skip_env = getenv("OPP_B3_SKIP_BIG") ? atoi(getenv("OPP_B3_SKIP_BIG")) : 0;    // tuning: no 160 KB tiles
+#endif
+    for (const Cand& c : cands) {
+#ifdef OPP_TUNING
+      if (only_env >= 0 && c.cfg != only_env && !(c.cfg == 2 && only_env != 2 && (long long)opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 64) <= 256)) continue;
+      if (skip_env && (c.cfg == 20 || c.cfg == 22)) continue;
+#endif
+      if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
+      if (c.bn == 192 && g.n_store % 192 != 0) continue;
+      // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles; 10 % faster than 128 x 256 on a grid of two full
+      // rounds (l1_out2a: 283 vs 315 us; one forward in flight +1.4 ... 2.8 % images/s), 5-8 % SLOWER per tile where the grid is half a round
+      // (125 vs 118 us at 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block), and with several forwards in flight
+      // it LOSES 1-2 % even on the big grid -- the chip is power-limited there, the eighth sub-tile of 128 x 256 multiplies zeros (cheap in
+      // energy, only costly in time) while the ring tile moves 25 % more fragment bytes per useful MFMA.  So: latency policy, grids of at
+      // least one full round (OPP_TILE_224=0 never, =2 always: the A/B switch of the tools).
+      if (c.bn == 224 && (g.n_store != 224 || g.n_real <= 0 || g.n_real > 208 || on224_env == 0 ||
+                          (on224_env != 2 && (g.tile_policy == OPP_TILES_THROUGHPUT || opp_cdiv(g.M, 128) < 256)))) continue;
+      const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
+      const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
+      long long est = full * (nk * c.chunk * c.wpc + c.fixed);
+      if (rem > 0) est += nk * c.chunk * ((rem + cus - 1) / cus) + c.fixed;
+      if (g.tile_policy == OPP_TILES_THROUGHPUT) {
+        // several forwards in flight (MatcherPool, bench --streams > 1): other streams' kernels fill the CUs a
+        // grid leaves idle, so what counts is the CU time a launch occupies, not its own latency: the larger tiles
+        // (64x64 per wave: fewer LDS bytes and barriers per MFMA) win even where they cover only part of the chip.
+        // Measured with 3 forwards in flight: +3.5 ... 6.5 % images/s, at -9 % for a single forward on its own.
+        if (tiles < 64 && c.cfg != 2) continue;
+        est = tiles * (nk * c.chunk + c.fixed / c.wpc);
+      }
+      if (best < 0 || est < best) {
+        best = est;
+        cfg = c.cfg;
+      }
+    }
+  }
+  return cfg;
+}
+
 int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   OppGemm g = g_in;
   {
@@ -1376,10 +1471,9 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       g.out_mul == 1.f && g.out_div == 1.f && g.vec_epilogue && g.n_store == g.ldc) {
     // few output tiles under a long K (shape-only decision, identical under both tile policies): 4 K slices on the 8-wave 128 x 128 tile
     constexpr int kSplits = 4;
-    const long long tiles128 = (long long)opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
     const int nkc = g.K / 32;
     const size_t need = (size_t)kSplits * g.M * g.ldc;
-    const bool by_shape = tiles128 <= 64 && nkc >= 32;
+    const bool by_shape = splitk_by_shape(g);
     if ((g.splitk_force > 0 || (g.splitk_force < 0 && by_shape)) && nkc >= kSplits && g.splitk_ws_floats >= need && need < (1ull << 31)) {
       OppGemm gs = g;
       gs.C = g.splitk_ws;
@@ -1404,89 +1498,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     }
   }
   const bool auto_cfg = cfg < 0;
-  if (cfg < 0) {
-    // Tile choice from the MI355X micro-bench (tools/conv_bench.py; 256 CUs x 4 SIMDs).  The
-    // 196(->224)-channel stages run as two column tiles (128 + 96 real columns): measured 4-12 %
-    // faster than dedicated 128x224 / 64x224 tiles (removed).
-    const int t0 = opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
-    const int t1 = opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 128);
-    if (t0 >= 384) cfg = 0;
-    else if (t1 >= 512) cfg = 1;
-    else cfg = 2;
-    // prefetch depth of the long-K convolutions on 128x128 tiles: 4 register sets when the grid
-    // is at most two workgroups per CU, else 3 (measured +8 % / +4 % over depth 2)
-    // (split operands: the MFMA phase is shorter, depth 2 measured best on every layer)
-    if (g.conv && g.K >= 768 && cfg == 0 && !split) cfg = t0 <= 512 ? 11 : 10;
-    // fp32, 128-column outputs of the 256x256-pixel layers: the 8-wave 128x128 tile (two waves per SIMD cover the
-    // prologue / epilogue of each other) measured 4-11 % faster than the deep-prefetch 4-wave one
-    if (!split && t0 >= 384 && g.n_store <= 128) cfg = 25;
-    if (g.prec == OPP_PREC_FP16X2) {
-      // fp16x2: 8-wave tiles (two waves per SIMD cover each other's LDS hand-over and barrier).  Policy:
-      // 128x128 (73 KB LDS, 120 registers: a second workgroup -- of this or of another stream's kernel --
-      // fits on the CU) wherever it still gives ~a workgroup per CU, else 64x128, else the 4-wave 64x64 tile.
-      // The 256x128 / 128x256 tiles (110 KB LDS) are 2-5 % faster for a kernel running alone on the two
-      // largest layers but cost 2.3 % of the throughput with three forwards in flight (no co-residency).
-      if (t0 >= 200) cfg = 25;          // 128x128 on 8 waves (32x64 per wave)
-      else if (t1 >= 512) cfg = 26;     // 64x128 on 8 waves
-      else cfg = 2;
-    } else if (g.prec == OPP_PREC_BF16X3) {
-      // bf16x3: the operand tiles are 1.5x larger (208 B per row and chunk), so the 128x128 tile already owns a CU
-      // (106 KB LDS) and the grid runs in whole rounds of <= 256 workgroups: pick the tile with the smallest
-      // estimated time = rounds x (K chunks x cycles per chunk + prologue / epilogue), constants from the MI355X
-      // micro-bench (tools/conv_bench.py --prec 2): the 256x128 / 128x256 8-wave tiles (160 KB LDS, 64x64 per wave)
-      // win wherever they still fill the chip in one round (256x256-pixel layers, QKV), 128x128 on the 128x128-pixel
-      // layers, 64x128 (80 KB, two workgroups per CU) / 64x64 below that.
-      // wpc = workgroups of this tile that share a CU (by LDS); co-resident workgroups share the matrix pipes, so a
-      // chunk then costs wpc x the stand-alone time.
-      struct Cand { int cfg, bm, bn, wpc, chunk, fixed; };
-      // (24: 128 x 192, for outputs that are whole 192-column tiles -- the body of a 196-channel layer: measured 228 us against 272 on the
-      // 128 x 256 tile at 256 x 256 pixels, profiles/r05_conv_bench_192_columns.txt)
-      // (27: 128 x 224 on four fragment sets, for outputs of exactly 224 stored columns -- the 196-channel layers in one column tile,
-      // 7 sub-tiles per SIMD and k-step instead of the 8 of 128 x 256)
-      static const Cand cands[] = {{24, 128, 192, 1, 4000, 16000}, {27, 128, 224, 1, 4250, 16000}, {22, 128, 256, 1, 4800, 16000}, {20, 256, 128, 1, 4800, 16000},
-                                   {25, 128, 128, 1, 2600, 13000}, {26, 64, 128, 2, 1400, 11000},
-                                   {2, 64, 64, 3, 1000, 9000}};
-      const long long nk = g.K / 32, cus = 256;
-      long long best = -1;
-      static const int on224_env = getenv("OPP_TILE_224") ? atoi(getenv("OPP_TILE_224")) : 1;         // A/B switch of the tools
-#ifdef OPP_TUNING
-      static const int only_env = getenv("OPP_B3_ONLY_CFG") ? atoi(getenv("OPP_B3_ONLY_CFG")) : -1;   // tuning: force one tile
-      static const int skip_env = getenv("OPP_B3_SKIP_BIG") ? atoi(getenv("OPP_B3_SKIP_BIG")) : 0;    // tuning: no 160 KB tiles
-#endif
-      for (const Cand& c : cands) {
-#ifdef OPP_TUNING
-        if (only_env >= 0 && c.cfg != only_env && !(c.cfg == 2 && only_env != 2 && (long long)opp_cdiv(g.M, 64) * opp_cdiv(g.n_store, 64) <= 256)) continue;
-        if (skip_env && (c.cfg == 20 || c.cfg == 22)) continue;
-#endif
-        if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
-        if (c.bn == 192 && g.n_store % 192 != 0) continue;
-        // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles; 10 % faster than 128 x 256 on a grid of two full
-        // rounds (l1_out2a: 283 vs 315 us; one forward in flight +1.4 ... 2.8 % images/s), 5-8 % SLOWER per tile where the grid is half a round
-        // (125 vs 118 us at 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block), and with several forwards in flight
-        // it LOSES 1-2 % even on the big grid -- the chip is power-limited there, the eighth sub-tile of 128 x 256 multiplies zeros (cheap in
-        // energy, only costly in time) while the ring tile moves 25 % more fragment bytes per useful MFMA.  So: latency policy, grids of at
-        // least one full round (OPP_TILE_224=0 never, =2 always: the A/B switch of the tools).
-        if (c.bn == 224 && (g.n_store != 224 || g.n_real <= 0 || g.n_real > 208 || on224_env == 0 ||
-                            (on224_env != 2 && (g.tile_policy == OPP_TILES_THROUGHPUT || opp_cdiv(g.M, 128) < 256)))) continue;
-        const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
-        const long long slots = cus * c.wpc, full = tiles / slots, rem = tiles % slots;
-        long long est = full * (nk * c.chunk * c.wpc + c.fixed);
-        if (rem > 0) est += nk * c.chunk * ((rem + cus - 1) / cus) + c.fixed;
-        if (g.tile_policy == OPP_TILES_THROUGHPUT) {
-          // several forwards in flight (MatcherPool, bench --streams > 1): other streams' kernels fill the CUs a
-          // grid leaves idle, so what counts is the CU time a launch occupies, not its own latency: the larger tiles
-          // (64x64 per wave: fewer LDS bytes and barriers per MFMA) win even where they cover only part of the chip.
-          // Measured with 3 forwards in flight: +3.5 ... 6.5 % images/s, at -9 % for a single forward on its own.
-          if (tiles < 64 && c.cfg != 2) continue;
-          est = tiles * (nk * c.chunk + c.fixed / c.wpc);
-        }
-        if (best < 0 || est < best) {
-          best = est;
-          cfg = c.cfg;
-        }
-      }
-    }
-  }
+  if (cfg < 0) cfg = choose_tile(g);
   // (the statistics scratch sits behind the staged C tile in the operand LDS: 4-wave tile for fp32 / fp16x2,
   // 8-wave tile for bf16x3, whose operand buffers are larger)
   OPP_CHECK_ARG(g.stat_rowmax == nullptr || (g.prec == OPP_PREC_BF16X3 ? (cfg == 25 || cfg == 20) : cfg == 0),
@@ -1552,3 +1564,10 @@ extern "C" int opp_debug_timestamps(void* buf) {
 }
 
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream) { return opp_gemm_launch_cfg(g, -1, stream); }
+
+// tile configuration the launcher would pick by itself (host only): >= 0 a tile config, + 1000 when a bf16x3 convolution of this shape runs as 4 K slices
+int opp_gemm_choose_tile(const OppGemm& g) {
+  int cfg = choose_tile(g);
+  if (g.conv && g.prec == OPP_PREC_BF16X3 && splitk_by_shape(g) && g.K / 32 >= 4) cfg = 1000 + 25;
+  return cfg;
+}

@@ -167,6 +167,8 @@ struct OppGemm {
 int opp_gemm_launch(const OppGemm& g, hipStream_t stream);
 // picks a tile configuration; exposed for tests / tuning (cfg < 0 = automatic)
 int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream);
+// the tile configuration the launcher would pick for g by itself (host only, no launch); + 1000 when a bf16x3 convolution of this shape runs as 4 K slices
+int opp_gemm_choose_tile(const OppGemm& g);
 
 #ifdef __HIPCC__
 // wave64 sum on the DPP path (no LDS round trips): quad butterflies, half-row / row mirrors, then the two

@@ -189,3 +189,49 @@ def test_smi_trace_summary_reads_amd_smi_samples():
     assert s["samples"] == 3 and s["busy_samples (gfx_activity >= 50 %)"] == 2
     assert s["socket_power_w"] == {"min": 1360.0, "mean": 1370.0, "max": 1380.0}
     assert s["gfx_clk_mhz_mean"]["mean"] == 2050.0 and s["gfx_clk_mhz_min"]["min"] == 2000.0
+
+
+def _k3(cin):
+    """packed K of a 3x3 convolution (opp_conv_packed_k): 32 n + (1..4) channels pack their last channels 8 taps to a chunk"""
+    g, t = divmod(cin, 32)
+    return (g * 9 + 2) * 32 if 1 <= t <= 4 else ((cin + 31) // 32) * 32 * 9
+
+
+# layer, M = output pixels, real / stored output channels, K, conv -> (latency policy, throughput policy) tile of the default arithmetic; + 1000 = four K slices.
+# Cross-checked against the kernel traces of both conditions (profiles/r05_kernel_stats_bench_streams1.csv: 5 launches of 256x128, 2 of 128x224, 6 + 4 of
+# 128x128, 2 of 64x128, 2 of 64x64 per forward; ..._default_streams4.csv: 10 of 128x256, 5 of 256x128, 4 K-sliced).
+TILE_POLICY_CASES = [
+    ("layer1 3x3 128->128 @256^2", 65536, 128, 128, 1152, 1, 20, 20),
+    ("layer1_outconv2.1 3x3 196->128 @256^2", 65536, 128, 128, _k3(196), 1, 20, 20),
+    ("layer1_outconv2.0 3x3 196->196 @256^2", 65536, 196, 224, _k3(196), 1, 27, 22),      # the 224-column ring tile: latency policy, full rounds only
+    ("layer1_outconv 1x1 128->196 @256^2", 65536, 196, 224, 128, 1, 27, 22),
+    ("layer2 3x3 196->196 @128^2", 16384, 196, 224, _k3(196), 1, 25, 22),                 # half a round: never the ring tile
+    ("layer2_outconv2.0 3x3 256->256 @128^2", 16384, 256, 256, 2304, 1, 25, 22),
+    ("layer2_outconv 1x1 196->256 @128^2", 16384, 256, 256, 224, 1, 26, 22),
+    ("layer3 3x3 256->256 @64^2", 4096, 256, 256, 2304, 1, 1025, 1025),                    # split-K is a shape decision, the same under both policies
+    ("layer3_outconv 1x1 256->256 @64^2", 4096, 256, 256, 256, 1, 2, 26),
+    ("batch of 4: layer2 3x3 196->196", 65536, 196, 224, _k3(196), 1, 27, 22),
+]
+
+
+@pytest.mark.parametrize("case", TILE_POLICY_CASES, ids=[c[0] for c in TILE_POLICY_CASES])
+def test_tile_policy_of_the_launcher(case):
+    """The launcher's own tile choice is a pure host function (opp_gemm_tile_for): pinned here per backbone layer shape and tile policy.
+    The 128 x 224 ring tile only where it measured faster: latency policy, 224 stored / <= 208 real columns, a grid of >= 256 tiles."""
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    _, M, n_real, n_store, K, conv, lat, thr = case
+    assert lib.opp_gemm_tile_for(M, n_real, n_store, K, conv, 2, 0) == lat
+    assert lib.opp_gemm_tile_for(M, n_real, n_store, K, conv, 2, 1) == thr
+
+
+def test_tile_policy_guards():
+    from onepose_plus_plus_amd import _lib
+    lib = _lib.load()
+    # unknown or too many real columns: the ring tile's "rows >= 208 are zero padding" premise does not hold -> 128 x 256
+    assert lib.opp_gemm_tile_for(65536, 0, 224, _k3(196), 1, 2, 0) == 22
+    assert lib.opp_gemm_tile_for(65536, 224, 224, _k3(196), 1, 2, 0) == 22
+    assert lib.opp_gemm_tile_for(65536, 196, 224, _k3(196), 1, 0, 0) != 27       # exact-fp32 arithmetic has no such tile
+    assert lib.opp_gemm_tile_for(65536, 196, 224, _k3(196), 1, 1, 0) != 27       # nor fp16x2
+    for bad in [(0, 1, 128, 128, 1, 2, 0), (128, 1, 128, 100, 1, 2, 0), (128, 1, 128, 128, 1, 5, 0), (128, 1, 128, 128, 1, 2, 7)]:
+        assert lib.opp_gemm_tile_for(*bad) < 0
