@@ -482,3 +482,32 @@ def test_linear_attention_backward_vs_fp64(B, L, S, H, D, masked):
     HipLinearAttention.apply(q2, k2, v2, qm, km).backward(go)
     torch.cuda.synchronize()
     assert torch.equal(q2.grad, q.grad) and torch.equal(k2.grad, k.grad) and torch.equal(v2.grad, v.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(50, 32, 7), (129, 96, 208), (1000, 1152, 130), (64, 160, 196), (300, 64, 224)])
+def test_ring_tile_edge_shapes_dense(M, K, N):
+    """128 x 224 ring tile (config 27) outside the shapes the model gives it: one chunk, odd chunk counts, partial row tiles, the 208-column limit.
+    Bit-identical to the 128 x 256 tile; more than 208 real columns are refused (rows >= 208 are never loaded)."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(7 * M + K + N)
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    if N > 208:
+        W[208:] = 0.0                                  # the caller of an explicit 27 vouches for zero rows >= 208 ...
+        got = ops.linear(A, W, 1, 27, h2=3)            # ... and then gets the 128 x 256 result
+        assert torch.equal(got, ops.linear(A, W, 1, 22, h2=3))
+        return
+    assert torch.equal(ops.linear(A, W, 1, 27, h2=3), ops.linear(A, W, 1, 22, h2=3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,ks,stride,H,Wd", [(32, 196, 1, 1, 8, 8), (196, 196, 3, 2, 17, 23), (256, 196, 3, 1, 10, 12), (128, 200, 3, 1, 9, 9)])
+def test_ring_tile_edge_shapes_conv(cin, cout, ks, stride, H, Wd):
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(1, cin, H, Wd, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * 0.05
+    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    a, pa = ops.conv2d(x, w, scale, bias, stride, None, 0, 1, 27, h2=3)
+    b, pb = ops.conv2d(x, w, scale, bias, stride, None, 0, 1, 25, h2=3)
+    assert torch.equal(a, b) and pa == 0.0 and pb == 0.0
