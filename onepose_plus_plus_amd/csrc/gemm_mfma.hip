@@ -23,6 +23,7 @@
 //  * Software pipeline: register-staged prefetch two chunks ahead, global loads and the LDS hand-over issued ONE PER MFMA
 //    SLOT, the barrier ahead of the last MFMA group so that its skew hides under MFMAs.
 //  * 8-wave tiles (two waves per SIMD) 256x128 / 128x256 / 128x128 / 64x128 / 64x256, 4-wave 64x64; XCD-aware tile order.
+//    128x192 (32x96 per wave) and 128x224 (32x128 | 32x96 per wave on FOUR rotating fragment sets, chunk_ring) for the 196-channel layers.
 //  * Epilogue through the idle operand LDS, 16 B per lane: folded-BN bias, residual (direct or bilinear x2
 //    align_corners=True), ReLU / LeakyReLU / elu+1, value scaling, LayerNorm of whole rows, dual-softmax statistics.
 //  * Dense split-K (grid.y) for the weight gradients of the training step (linear_bwd.hip).
@@ -1219,11 +1220,11 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   // (fp16x2 keeps the 4-wave 128x128 tile: its score GEMM with the fused statistics runs on it)
   // 128 x 192 on 8 waves (32 x 96 per wave, 219 registers, 133 KB of LDS): the 192-column body of the 196-channel layers, whose last 4
   // columns come from conv_tail.hip (round 5; config 24)
-  constexpr bool kTuning192 = BM == 128 && (BN == 192 || BN == 224) && NT == 512 && PREC == OPP_PREC_BF16X3;   // (and the 224-column ring tile)
+  constexpr bool kNarrowB3 = BM == 128 && (BN == 192 || BN == 224) && NT == 512 && PREC == OPP_PREC_BF16X3;   // (and the 224-column ring tile)
   constexpr bool ok = (PREC == OPP_PREC_FP32 && BN != 192 && BN != 224) ||
                       (DEPTH == 2 && (NT == 512 || (BM == 64 && BN == 64) || (PREC == OPP_PREC_FP16X2 && BM == 128 && BN == 128)) &&
-                       (BN == 128 || BN == 64 || BN == 256 || kTuning192) &&
-                       (PREC != OPP_PREC_BF16X3 || (BN * 12) % NT == 0 || kTuning192) && (PREC != OPP_PREC_BF16X3 || BM * BN / NT <= 64 || kTuning192));
+                       (BN == 128 || BN == 64 || BN == 256 || kNarrowB3) &&
+                       (PREC != OPP_PREC_BF16X3 || (BN * 12) % NT == 0 || kNarrowB3) && (PREC != OPP_PREC_BF16X3 || BM * BN / NT <= 64 || kNarrowB3));
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
