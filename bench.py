@@ -227,11 +227,15 @@ def run_dry(args):
             d.barrier()
     run_steps(max(args.warmup, 1) * ips)
     last, own, elapsed = timed_region(run_steps, args.steps * ips, barrier, lambda: None)
-    elapsed, devs, seen = gather_ranks(d, torch, dev, elapsed, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid(),
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    elapsed, devs, seen = gather_ranks(d, torch, dev, elapsed, {"rank": rank, "local_rank": local_rank, "pid": os.getpid(),
+                                                              "device": local_rank,        # what run() hands torch.cuda.set_device
+                                                              "visible": os.environ.get("HIP_VISIBLE_DEVICES"),
+                                                              "host_affinity": "dry run: %d cpus allowed" % len(os.sched_getaffinity(0)),
                                                               "images_per_s": round(args.steps * ips / own, 2), "weights_checksum": checksum})
     if rank == 0:
         total = args.steps * ips * world
-        print(json.dumps({"metric": "DRY RUN (no GPU work): multi-rank skeleton of bench.py over gloo", "value": round(total / elapsed, 3),
+        print(bounded_dumps({"metric": "DRY RUN (no GPU work): multi-rank skeleton of bench.py over gloo", "value": round(total / elapsed, 3),
                           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "data": "none", "config": {"workload": "dry run", "images_per_step": ips, "per_rank_images_per_s": per_rank_summary(devs),
@@ -429,11 +433,17 @@ def run(args):
 
     if rank == 0:
         total = args.steps * ips * world
-        if roof is not None and legs:      # compact copies of the secondary legs inside `roofline` (driver-side parsers keep it whole)
+        if roof is not None and legs:      # compact copies of the secondary legs inside `roofline` (the sidecar keeps both)
             roof["legs"] = compact_legs(legs)
-        flops_img = 2 * (126.726e9 + 6 * (4096 + args.n_points) * 671744 + args.n_points * 4096 * 256)
+        # FLOPs of one image: what the reference computes per image and what THIS run executed per image -- with the
+        # per-object token cache on, layer 0 on the 3D stream + its layer-1 projections / KV sums are not redone per image and are
+        # NOT counted in any roofline fraction of this line
+        ref_flops = flops_per_image(args.n_points, cached=False)
+        obj = model._rt.get("obj")       # (key, tokens, sources, event, transformer-prefix blob or None)
+        cache_on = bool(getattr(model, "cache_object_tokens", True)) and obj is not None and obj[4] is not None
+        flops_img = flops_per_image(args.n_points, cached=cache_on)
         peak = MFMA_PEAK[precision]
-        out = {
+        detail = {
             "metric": "query images/sec (2D-3D match fwd) at 512x512 img x 5k pts",
             "value": round(total / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -444,26 +454,179 @@ def run(args):
             "config": {"workload": "%s: single object, %dx%d image x %d points, %s, B=1 per forward, "
                                    "a step = %d forwards per GPU, %d forward(s) in flight per GPU on separate HIP streams, one object per GPU; image and "
                                    "descriptor banks resident in HBM; the image-independent work on the resident object (keypoint-MLP encoding of the "
-                                   "bank, layer-0 self-attention of the 3D stream, its layer-1 projections and KV sums: 2.6 %% of the FLOPs, still counted "
-                                   "in model_gflop_per_image) is cached per object -- `object_token_cache_off` is the leg without it; thr %.2f gives M = %d "
+                                   "bank, layer-0 self-attention of the 3D stream, its layer-1 projections and KV sums: 2.6 %% of the reference's FLOPs, "
+                                   "NOT counted in executed_gflop_per_image) is cached per object -- `object_token_cache_off` is the leg without it; thr %.2f gives M = %d "
                                    "matches on these random weights (the conf matrix is still fully materialised)"
                                    % ("configs[2] / [3] shape" if args.fine else "configs[1]", args.hw, args.hw, args.n_points,
                                       "full coarse-to-fine (match-driven fine branch)" if args.fine else "coarse-match only", ips, n_streams,
                                       args.thr, matches_last),
+                       "workload_short": "%s: %dx%d x %d pts, %s, B=1, %d fwd/step, %d stream(s)/GPU, banks resident, object-token cache %s"
+                                         % ("configs[2]" if args.fine else "configs[1]", args.hw, args.hw, args.n_points,
+                                            "coarse-to-fine" if args.fine else "coarse-match only", ips, n_streams, "on" if cache_on else "off"),
                        "images_per_step": ips, "streams_per_gpu": n_streams,
                        "per_rank_images_per_s": per_rank_summary(devs), "gemm_precision": precision, "tile_policy": policy, "fpn_overlap": bool(overlap),
-                       "matches_last_step": matches_last, "object_token_cache": True,
+                       "matches_last_step": matches_last, "object_token_cache": cache_on,
                        "n_ranks_seen": n_ranks_seen, "rank_devices": devs,
-                       "model_gflop_per_image": round(flops_img / 1e9, 1),
+                       "reference_gflop_per_image": round(ref_flops / 1e9, 1),
+                       "executed_gflop_per_image": round(flops_img / 1e9, 1),
                        "model_tflops": round(flops_img * total / elapsed / 1e12, 2),
                        "model_frac_of_mfma_peak": round(flops_img * total / elapsed / 1e12 / world / peak, 4),
                        "mfma_peak_tflops_for_this_arithmetic": round(peak, 1),
                        **legs},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        off = (legs.get("object_token_cache_off_leg") or {}).get("value")
+        if off:           # first-class: the same workload doing exactly the reference's per-image work (cache off), fraction on ALL its FLOPs
+            detail["config"]["value_cache_off"] = off
+            detail["config"]["frac_cache_off"] = round(ref_flops * off / 1e12 / peak, 4)
+        where = write_detail(detail)
+        print(bounded_dumps(compact_line(detail, where)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 6000            # bytes of the ONE JSON line of rank 0 (the driver keeps the last ~8 KB of stdout); the rest is the sidecar
+# per-token multiply-adds of one encoder layer: x side 532,480 + source side 139,264; QKV projections 3 x 65,536; KV sums 8,192
+MACS_LAYER_TOKEN, MACS_QKV_TOKEN, MACS_KV_TOKEN = 671744, 196608, 8192
+
+
+def flops_per_image(n_points, cached):
+    """Algorithmic FLOPs of one coarse forward.  cached = True: minus what a resident object's token cache keeps out of
+    the per-image work (opp_object_prefix: layer 0 on the 3D stream, its layer-1 QKV projections and KV / Ksum reduction)."""
+    f = 2.0 * (126.726e9 + 6 * (4096 + n_points) * MACS_LAYER_TOKEN + n_points * 4096 * 256)
+    if cached:
+        f -= 2.0 * n_points * (MACS_LAYER_TOKEN + MACS_QKV_TOKEN + MACS_KV_TOKEN)
+    return f
+
+
+def write_detail(detail):
+    """Everything the run measured -> bench_detail.json next to this file (and gpurun_out/ when it exists, so that it travels back
+    from a GPU box).  -> the path written, relative to the repo root, or None"""
+    where = None
+    for d in ([os.environ["OPP_BENCH_DETAIL"]] if os.environ.get("OPP_BENCH_DETAIL") else
+              [os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")]):
+        try:
+            if os.path.isdir(os.path.dirname(d) or "."):
+                with open(d, "w") as f:
+                    json.dump(detail, f, indent=1)
+                where = where or os.path.relpath(d, ROOT)
+        except OSError:
+            pass
+    return where
+
+
+def bounded_dumps(obj, limit=LINE_LIMIT):
+    """json.dumps that refuses to print a line the driver's stdout tail would cut"""
+    line = json.dumps(obj)
+    if len(line) > limit:
+        raise SystemExit("bench.py: JSON line of %d bytes exceeds the %d-byte bound" % (len(line), limit))
+    return line
+
+
+def _traffic_bytes(t):
+    """PMC summary entry -> HBM bytes per launch (one launch shape), or None"""
+    if isinstance(t, dict) and "hbm_bytes_per_launch" in t:
+        return t["hbm_bytes_per_launch"]
+    if isinstance(t, dict) and "per_launch_shape" in t:          # several shapes: launch-weighted mean
+        sh = [v for v in t["per_launch_shape"].values() if "hbm_bytes_per_launch" in v]
+        n = sum(v.get("launches_sampled", 1) for v in sh)
+        return int(sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in sh) / n) if n else None
+    return None
+
+
+def _short_symbol(m):
+    """`opp_gemm_kernel<128, 128, 4, 2, true, 0, 2, 2>` -> `gemm<128,128,4,2,conv>`; other kernels keep their name minus `_kernel`"""
+    sym = m.get("symbol") or ""
+    if sym and sym[0].isdigit():
+        a = [x.strip() for x in sym.split(",")]
+        return "gemm<%s,%s,%s,%s,%s>" % (a[0], a[1], a[2], a[3], "conv" if a[4] == "true" else "dense")
+    if sym.startswith("opp_gemm_kernel<"):
+        return "gemm<128,128,4,2,conv>x4K"
+    return sym.replace("_kernel", "")
+
+
+def compact_line(detail, detail_path=None, limit=LINE_LIMIT):
+    """The ONE line rank 0 prints: the contract's keys, the dominant kernel's roofline with numbers only, a <= 8-row table of the
+    other kernels, the headline figures of the secondary legs -- never more than `limit` bytes.  Prose, per-shape traffic tables and
+    full legs live in the sidecar (`detail`)."""
+    c = detail.get("config") or {}
+    out = {k: detail.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_image",
+                                      "higher_is_better", "scaling", "vs_baseline")}
+    prec = c.get("gemm_precision")
+    out["dtype"] = {"bf16x3": "f32 (operands as exact bf16 triples, f32 accumulate)", "fp32": "f32"}.get(prec, str(detail.get("dtype"))[:60])
+    out["data"] = "synthetic"
+    cfg = {"workload": (c.get("workload_short") or c.get("workload") or "")[:200]}
+    for k in ("images_per_step", "streams_per_gpu", "gemm_precision", "tile_policy", "object_token_cache", "matches_last_step",
+              "n_ranks_seen", "per_rank_images_per_s", "reference_gflop_per_image", "executed_gflop_per_image", "model_tflops",
+              "model_frac_of_mfma_peak", "mfma_peak_tflops_for_this_arithmetic", "value_cache_off", "frac_cache_off"):
+        if c.get(k) is not None:
+            cfg[k] = c[k]
+    devs = c.get("rank_devices") or []
+    if len(devs) > 1:         # [rank, local_rank, device, images/s] per rank; names / uuids / pids / affinity: sidecar
+        cfg["ranks"] = [[d.get("rank"), d.get("local_rank"), d.get("device"), d.get("images_per_s")] for d in devs]
+    out["config"] = cfg
+    r = detail.get("roofline")
+    roof = None
+    if r:
+        roof = {"bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+                "traffic": _traffic_bytes(r.get("traffic")), "kernel": _short_symbol(r), "avg_us": r.get("avg_launch_us"),
+                "launches_per_forward": r.get("launches_per_forward"),
+                **({"alg_gflop_per_launch": r["alg_gflop_per_launch"]} if "alg_gflop_per_launch" in r else
+                   {"alg_mbytes_per_launch": r.get("alg_mbytes_per_launch")}),
+                "frac_event_corrected": r.get("frac_event_corrected"),
+                "how": "HIP events on the launch stream, 1 forward in flight"}
+        top = []
+        for m in (r.get("other_kernels") or []):
+            top.append({"sym": _short_symbol(m), "us": m.get("us_per_forward"), "n": m.get("launches_per_forward"),
+                        "frac": m.get("frac"), "of": "mfma" if m.get("bound") == "mfma" else "hbm"})
+        roof["top"] = top[:8]
+        ss = next((m for m in [r] + (r.get("other_kernels") or []) if (m.get("symbol") or "").startswith("gemm_ss_kernel<3>")), None)
+        if ss:                # the kernel north_star names: coarse score GEMM
+            roof["score_gemm"] = {"us": ss.get("avg_launch_us"), "frac": ss.get("frac"), "frac_event_corrected": ss.get("frac_event_corrected"),
+                                  "traffic": _traffic_bytes(ss.get("traffic"))}
+        if r.get("launches_per_coarse_forward") is not None:
+            roof["launches_per_coarse_forward"] = r["launches_per_coarse_forward"]
+    out["roofline"] = roof
+    cb = detail.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "one_thread": cb.get("one_thread_images_per_s"), "sample": (cb.get("sample_short") or cb.get("sample") or "")[:240]}
+        if cb.get("reference_in_build_container") is not None:
+            out["cpu_baseline"]["reference_in_build_container"] = cb["reference_in_build_container"]
+    else:
+        out["cpu_baseline"] = None
+    legs = {}
+    oa = c.get("other_arithmetics") or {}
+    if (oa.get("fp32") or {}).get("value") is not None:
+        legs["fp32_images_per_s"] = oa["fp32"]["value"]
+    for pol in ("latency", "throughput"):
+        if (c.get(pol + "_tiles_leg") or {}).get("value") is not None:
+            legs[pol + "_tiles_images_per_s"] = c[pol + "_tiles_leg"]["value"]
+    f = c.get("fine_leg") or {}
+    if "ms_per_forward" in f:
+        legs["fine"] = {k: f.get(k) for k in ("matches", "ms_per_forward", "images_per_s", "fine_stage_ms", "fine_stage_frac_of_mfma_peak")}
+    for name, key in (("train", "train_leg"), ("train_n15000", "train_leg_n15000")):
+        t = c.get(key) or {}
+        if "step_ms" in t:
+            legs[name] = {"step_ms": t["step_ms"], "forward_ms": t.get("forward_ms"), "samples_per_s": t.get("step_samples_per_s"),
+                          "frac": (t.get("roofline") or {}).get("frac"),
+                          "wgrad_frac": ((t.get("roofline") or {}).get("dominant_kernel") or {}).get("frac")}
+            if name == "train":
+                legs[name]["arith"] = "bf16x3 = f32-exact operands (reference trains f32, lightning_model:59); no bf16 autocast offered"
+        elif "error" in t:
+            legs[name] = {"error": str(t["error"])[:80]}
+    if legs:
+        out["legs"] = legs
+    if detail_path:
+        out["detail"] = detail_path
+    # hard bound: shed optional parts until the line fits
+    for shed in (lambda: out.get("legs", {}).pop("train_n15000", None), lambda: out.get("legs", {}).pop("fine", None),
+                 lambda: roof and roof.__setitem__("top", roof["top"][:4]), lambda: out.pop("legs", None),
+                 lambda: roof and roof.pop("top", None), lambda: cfg.pop("ranks", None)):
+        if len(json.dumps(out)) <= limit:
+            break
+        shed()
+    return out
 
 
 def compact_legs(legs):
@@ -643,7 +806,7 @@ def other_legs(torch, dev, cfg, models, run_steps, step, precision, n_streams, a
     coarse-to-fine forward on a bank with ~1500 confident matches (fine stage timed with HIP events)."""
     legs = {}
     other = {}
-    for p in ("fp32", "fp16x2_all"):
+    for p in ("fp32",):
         if p == precision:
             continue
         for m in models:
@@ -1107,6 +1270,11 @@ def cpu_baseline(torch, cfg, sd, args, make_inputs):
     torch.set_num_threads(used)
     return {"value": round(1.0 / med, 4), "unit": "images/s", "cores": used, "kind": "port", "one_thread_images_per_s": round(1.0 / one, 4),
             "thread_calibration_s_per_forward": calib,
+            # the reference module itself cannot travel to the GPU box; its figure where it can run (build container, 8 cores)
+            "reference_in_build_container": {"value": 0.90, "unit": "images/s", "cores": 8, "source": "BASELINE.md: stubbed reference module, N=5000"},
+            "sample_short": "%d forwards of this workload through oracle/onepose_oracle.py = PORT OF the reference fp32 PyTorch CPU path (pinned "
+                            "bit-level to it by tests/test_oracle_golden.py), %d of %d threads (fastest of 8..128), median; min %.3f s"
+                            % (len(times), best[0], avail, min(times)),
             "sample": "%d forwards of the same %dx%d x %d-pt workload through oracle/onepose_oracle.py "
                       "(fp32 PyTorch CPU, %d of %d available threads: the fastest of {8, 16, 32, 64, 128} on this full-size workload), median; min %.3f s"
                       % (len(times), args.hw, args.hw, args.n_points, best[0], avail, min(times))}
