@@ -399,6 +399,8 @@ def run(args):
 
     last, own_elapsed, elapsed = timed_region(run_steps, args.steps * ips, barrier, lambda: torch.cuda.synchronize(dev))
     matches_last = int(last["mconf"].numel())
+    obj = model._rt.get("obj")       # (key, tokens, sources, event, transformer-prefix blob or None) as the timed region left it
+    cache_on = bool(getattr(model, "cache_object_tokens", True)) and obj is not None and obj[4] is not None
     props = torch.cuda.get_device_properties(dev)
     elapsed, devs, n_ranks_seen = gather_ranks(dist, torch, dev, elapsed, {
         "rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": props.name,
@@ -439,8 +441,6 @@ def run(args):
         # per-object token cache on, layer 0 on the 3D stream + its layer-1 projections / KV sums are not redone per image and are
         # NOT counted in any roofline fraction of this line
         ref_flops = flops_per_image(args.n_points, cached=False)
-        obj = model._rt.get("obj")       # (key, tokens, sources, event, transformer-prefix blob or None)
-        cache_on = bool(getattr(model, "cache_object_tokens", True)) and obj is not None and obj[4] is not None
         flops_img = flops_per_image(args.n_points, cached=cache_on)
         peak = MFMA_PEAK[precision]
         detail = {
@@ -562,7 +562,7 @@ def compact_line(detail, detail_path=None, limit=LINE_LIMIT):
         if c.get(k) is not None:
             cfg[k] = c[k]
     devs = c.get("rank_devices") or []
-    if len(devs) > 1:         # [rank, local_rank, device, images/s] per rank; names / uuids / pids / affinity: sidecar
+    if devs:                  # [rank, local_rank, device, images/s] per rank; names / uuids / pids / affinity: sidecar
         cfg["ranks"] = [[d.get("rank"), d.get("local_rank"), d.get("device"), d.get("images_per_s")] for d in devs]
     out["config"] = cfg
     r = detail.get("roofline")

@@ -55,7 +55,8 @@ typedef struct opp_config {
    *     (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 significant bits, fp32 exponent range, no
    *     range restriction), six bf16 MFMAs per product (the dropped mid*lo, lo*mid, lo*lo terms are <= 2^-26 |a||b|,
    *     below fp32's own rounding), 6/16 of the fp32 MFMA cycles.  Not narrower than fp32.
-   * 1 = fp16x2 split (opt-in fast mode, NARROWER than fp32): x ~ hi + lo fp16 (22-bit mantissa), three fp16 MFMAs
+   * 1 = fp16x2 split (NARROWER than fp32; TUNING LIBRARY ONLY since round 6 -- the product build has no fp16x2 kernels and
+   *     opp_create refuses 1 and 2, see opp_supports_precision): x ~ hi + lo fp16 (22-bit mantissa), three fp16 MFMAs
    *     per product, 3/16 of the fp32 MFMA cycles.  Activations must stay inside the fp16 range (|x| < 65504;
    *     the kernels flag non-finite outputs, see opp_forward_coarse `count[1]`), values below 2^-3 keep an
    *     absolute 2^-25 error; weights are pre-scaled per matrix and unrestricted.  The coarse score GEMM stays fp32.
@@ -93,6 +94,9 @@ int opp_version(void);
 /* sha256 (hex) of the sources this binary was built from (every file of csrc/ + this header), baked in by the build;
  * the Python binding compares it with the sources next to the library and refuses a stale binary. */
 const char* opp_source_hash(void);
+/* 1 when this binary can run opp_config.gemm_precision `p` (0 fp32 and 3 bf16x3: always; 1 / 2 fp16x2: only a library built with
+ * `python -m onepose_plus_plus_amd.build --tuning`), else 0.  Not a reference interface: the reference has one arithmetic (fp32). */
+int opp_supports_precision(int gemm_precision);
 
 /* ---- model handle + weights -------------------------------------------------------------
  * Replaces: OnePosePlus_model.__init__ + load_state_dict (OnePosePlusModel.py:26-94,

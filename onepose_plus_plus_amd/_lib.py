@@ -46,6 +46,7 @@ SIGNATURES = {
     "opp_last_error": (c_char_p, []),
     "opp_version": (c_int, []),
     "opp_source_hash": (c_char_p, []),
+    "opp_supports_precision": (c_int, [c_int]),
     "opp_profile_event_overhead": (c_int, [c_int, POINTER(ctypes.c_double), c_void_p]),
     "opp_profile_empty_kernel": (c_int, [c_int, POINTER(ctypes.c_double), c_void_p]),
     "opp_profile_event_calibration": (c_int, [c_int, ctypes.c_double, POINTER(ctypes.c_double), POINTER(ctypes.c_double), c_void_p]),

@@ -242,6 +242,13 @@ extern "C" int opp_create(const opp_config* cfg, opp_ctx** out) {
   OPP_CHECK_ARG(!cfg->kpt_enc_enable || (cfg->kpt_enc_dims[0] == 32 && cfg->kpt_enc_dims[1] == 64 && cfg->kpt_enc_dims[2] == 128),
                 "keypoint encoder must be [32,64,128]");
   OPP_CHECK_ARG(cfg->gemm_precision >= 0 && cfg->gemm_precision <= 3, "gemm_precision must be 0..3");
+#ifndef OPP_TUNING
+  if (cfg->gemm_precision == 1 || cfg->gemm_precision == 2) {
+    opp_set_error("gemm_precision %d (fp16x2, narrower than fp32) exists in the tuning library only (python -m onepose_plus_plus_amd.build --tuning)",
+                  cfg->gemm_precision);
+    return OPP_ERR_UNSUPPORTED;
+  }
+#endif
   OPP_CHECK_ARG(cfg->tile_policy == OPP_TILES_LATENCY || cfg->tile_policy == OPP_TILES_THROUGHPUT, "tile_policy must be 0 or 1");
   OPP_CHECK_ARG(cfg->encoder_fusion >= 0 && cfg->encoder_fusion <= 2, "encoder_fusion must be 0, 1 or 2");
   OPP_CHECK_ARG(cfg->fpn_overlap == 0 || cfg->fpn_overlap == 1, "fpn_overlap must be 0 or 1");
@@ -603,11 +610,11 @@ struct SplitKScope {
     t_splitk_ws_floats = prev_floats;
   }
 };
-// would the DENSE convolution d over `pixels` output pixels run as K slices (opp_gemm_launch_cfg: <= 64 tiles of 128 x 128 under >= 32
-// K chunks, bf16x3, the A/B switch OPP_CONV_SPLITK aside)?
+// would the DENSE convolution d over `pixels` output pixels run as K slices?  The launcher's own shape rule (opp_conv_splitk_by_shape,
+// gemm_mfma.hip) on the dense problem; its remaining conditions (bf16x3, scratch present, plain epilogue, full-width rows) hold for the
+// two layers asked about whenever the dense map is evaluated through opp_forward_coarse.
 bool conv_splits_by_shape(const ConvDesc& d, size_t pixels, int prec) {
-  const long long tiles128 = (long long)((pixels + 127) / 128) * ((d.cout_pad() + 127) / 128);
-  return prec == OPP_PREC_BF16X3 && tiles128 <= 64 && d.k_len() / 32 >= 32;
+  return prec == OPP_PREC_BF16X3 && opp_conv_splitk_by_shape((long long)pixels, d.cout_pad(), d.k_len());
 }
 
 // pad < 0: "same" padding ks / 2 (every convolution of the reference); pad = 0: a VALID convolution over Bn small patches (match-driven

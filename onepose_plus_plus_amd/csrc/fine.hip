@@ -185,15 +185,21 @@ __global__ __launch_bounds__(256) void fine_head_bwd_kernel(const float* __restr
   const float dsim = lane < WW ? temp * (p * (a - pa)) : 0.f;               // includes the temperature factor of sim
   if (!live) return;
   // lanes over channels from here on: d f3[c] = sum_r dsim_r win[r][c],  d win[r][c] = dsim_r f3[c]
-  for (int c = lane; c < C; c += 64) {
-    const float fc = f[c];
+  // (every lane of the wave stays in the loop -- the shuffle reads dsim of lanes r < WW, which must be active -- and only the
+  // loads / stores are guarded: C need not be a multiple of 64)
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    const bool okc = c < C;
+    const float fc = okc ? f[c] : 0.f;
     float acc = 0.f;
     for (int r = 0; r < WW; ++r) {
       const float dr = __shfl(dsim, r, 64);
-      acc = fmaf(dr, win[((size_t)m * WW + r) * ldw + c], acc);
-      gwin[((size_t)m * WW + r) * ldw + c] = dr * fc;
+      if (okc) {
+        acc = fmaf(dr, win[((size_t)m * WW + r) * ldw + c], acc);
+        gwin[((size_t)m * WW + r) * ldw + c] = dr * fc;
+      }
     }
-    gf3[(size_t)m * ld3 + c] = acc;
+    if (okc) gf3[(size_t)m * ld3 + c] = acc;
   }
 }
 

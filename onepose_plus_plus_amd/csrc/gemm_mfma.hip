@@ -1256,7 +1256,11 @@ int launch_cfg(const OppGemm& g, hipStream_t stream) {
 #endif
   switch (g.prec) {
     case OPP_PREC_FP32: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_FP32>(g, stream, extra_lds);
+#ifdef OPP_TUNING            // narrower than fp32: instantiated in the tuning library only (round 6)
     case OPP_PREC_FP16X2: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_FP16X2>(g, stream, extra_lds);
+#else
+    case OPP_PREC_FP16X2: opp_set_error("gemm: fp16x2 operands are built into the tuning library only"); return OPP_ERR_UNSUPPORTED;
+#endif
     case OPP_PREC_BF16X3: return launch_prec<BM, BN, WAVES_M, WAVES_N, DEPTH, OPP_PREC_BF16X3>(g, stream, extra_lds);
     default: opp_set_error("gemm: unknown operand precision %d", g.prec); return OPP_ERR_INVALID;
   }
@@ -1324,10 +1328,13 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
 }  // namespace
 
 // few output tiles under a long K: the convolution runs as 4 K slices (shape-only, identical under both tile policies)
-static bool splitk_by_shape(const OppGemm& g) {
-  const long long tiles128 = (long long)opp_cdiv(g.M, 128) * opp_cdiv(g.n_store, 128);
-  return tiles128 <= 64 && g.K / 32 >= 32;
+// (ONE predicate for the launcher and for the match-driven fine branch of api.hip, whose bit-identity with the dense map rests on both
+// walking K in the same slices)
+bool opp_conv_splitk_by_shape(long long M, int n_store, int K) {
+  const long long tiles128 = ((M + 127) / 128) * (long long)opp_cdiv(n_store, 128);
+  return tiles128 <= 64 && K / 32 >= 32;
 }
+static bool splitk_by_shape(const OppGemm& g) { return opp_conv_splitk_by_shape(g.M, g.n_store, g.K); }
 
 // The launcher's own tile choice (tile_cfg < 0) as a pure function of the problem shape, the operand arithmetic and the tile policy:
 // no device, no launch -- opp_gemm_tile_for (api.hip) exports it so that the policy is pinned by CPU tests (tests/test_host_logic.py).
@@ -1388,7 +1395,7 @@ static int choose_tile(const OppGemm& g) {
       if (skip_env && (c.cfg == 20 || c.cfg == 22)) continue;
 #endif
       if (c.bn == 256 && g.n_store <= 128) continue;   // half the tile would be padding
-      if (c.bn == 192 && g.n_store % 192 != 0) continue;
+      if (c.bn == 192 && (!g.conv || g.n_store % 192 != 0)) continue;      // measured on convolution bodies only (conv_tail path): never a silent choice for dense GEMMs
       // measured (profiles/r05_conv_bench_224_columns.txt): bit-identical to the other tiles; 10 % faster than 128 x 256 on a grid of two full
       // rounds (l1_out2a: 283 vs 315 us; one forward in flight +1.4 ... 2.8 % images/s), 5-8 % SLOWER per tile where the grid is half a round
       // (125 vs 118 us at 128 x 128 pixels: 32 x 128 per wave reads every B fragment for ONE row block), and with several forwards in flight

@@ -103,29 +103,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_kernel(const OppGemmSS g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
-  // two workgroups share a CU: a static priority for every other workgroup of an XCD de-phases the pair (one's MFMA loop
-  // under the other's prologue / epilogue).  blockIdx is scalar: the branch is wave-uniform, as s_setprio requires.
-  if (g.prio_mode == 1 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(1);
-  if (g.prio_mode == 2 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(3);
-  // De-phasing of the two workgroups that share a CU (r05).  They are dispatched together and, left alone, stay in lock step: both in the K
-  // loop (each at half the matrix-pipe rate), then both in the epilogue (matrix pipe idle) -- a tile then costs loop + epilogue instead of
-  // max(loop, epilogue).  The first generation of workgroups (the first 2 x 256) is shifted by roughly half a tile: the workgroup whose
-  // wave 0 sits in an odd hardware wave slot (HW_ID.wave_id: the second of the two residents of its SIMD) sleeps before its prologue; every
-  // later workgroup inherits the phase of the slot it is dispatched into.  Modes 3 / 4 / 5: 8 / 16 / 24 k cycles.
-  if (g.prio_mode >= 3 && blockIdx.x < g.dephase_blocks) {
-    int* flag = reinterpret_cast<int*>(smem);
-    if (tid == 0) {
-      unsigned hw;
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-      *flag = (int)(hw & 1u);
-    }
-    __syncthreads();
-    const int odd = *flag;
-    __syncthreads();
-    if (odd)
-      for (int i = 0; i < g.prio_mode - 2; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
   // XCD-aware tile order (workgroup b runs on XCD b % 8; speed only -- every output is indexed by tile coordinates): an XCD gets
   // a contiguous range of a linear order that walks STRIPS of RS row panels column by column (row fastest).  The ~64 tiles an
   // XCD has in flight then cover RS row panels x 8 column panels = 16 operand panels of 192 KB (3 MB of its 4 MB L2), every
@@ -563,10 +540,373 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_kernel(const OppGemmSS g) {
 #endif
 }
 
+
+// ---- persistent single-sweep kernel (r06): statistics + score matrix, OPP_SS_STATS_STORE ------------------------------------------
+// Same tile, same K loop and the same accumulation sequence as gemm_ss_kernel (the score tiles are bit-identical); what changes is what a
+// workgroup does BETWEEN K loops.  Measured on the one-tile-per-workgroup kernel (tools/gemm_ss_probe.py, 4096 x 5000 x 256): prologue 7.1 k
+// cycles (every workgroup of a generation asks for its first 72 KB at once), K loop 23.7 k, epilogue 9 k, and 1280 tiles on 512 resident
+// workgroups = 2.5 generations of which the last runs alone.  Here 2 workgroups per CU stay resident and walk a static tile list
+// (XCD x: its contiguous range of the strip order, workgroup idx of the XCD takes tiles idx, idx + 64, idx + 128):
+//   * the first k16-stage of the NEXT tile is fetched under the epilogue of the current one: the epilogue stages the tile through LDS in
+//     two halves of 64 columns (33 KB instead of 66), which leaves the third operand slot free for that stage;
+//   * the per-row statistics (max, sum exp) of the two halves are merged online in the registers of the thread that owns the row
+//     (fixed order: a function of the row's values only, as before -- duplicated rows still get bit-equal statistics);
+//   * the second resident of a CU (the upper half of an XCD's workgroups: they are dispatched after every CU has its first) starts
+//     `g.delay` x 64 cycles late, so that one workgroup's K loop runs under the other's epilogue from the first tile on, and takes the
+//     shorter tile list (2 of the CU's 5 tiles at 4096 x 5000).
+// LDS: 3 slots of 24 KB + 4 KB of statistics scratch that never aliases the slots = 76 KB, two workgroups per CU.
+constexpr int PT_TS = BM + 4;                                   // staging row stride (floats)
+constexpr int PT_HC = BN / 2;                                   // columns per staged half
+constexpr int PT_MISC = NS * SLOT;                              // byte offset of the statistics scratch
+constexpr size_t PT_LDS = (size_t)NS * SLOT + 4096;
+static_assert(PT_HC * PT_TS * 4 <= 2 * SLOT, "a staged half tile must leave the third operand slot free");
+
+struct SsTile {
+  unsigned a_voff[A_LD], b_voff[B_LD];
+  int soffA0, soffB0, m0, n0, tile_m, tile_n;
+};
+
+__global__ __launch_bounds__(NT, 2) void gemm_ss_persist_kernel(const OppGemmSS g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int ntiles = tiles_m * tiles_n;
+  // static tile list: workgroup b runs on XCD b % 8 (observed dispatch order: speed only); the XCD owns a contiguous range of the strip order
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int wgs_x = ((int)gridDim.x + 7 - xcd) >> 3;             // workgroups of this launch on the XCD
+  const int tq = ntiles >> 3, tr = ntiles & 7;
+  const int t_first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq), t_count = tq + (xcd < tr ? 1 : 0);
+  if (idx >= t_count) return;
+  // the second resident of a CU starts late (see above); wave-uniform
+  if (g.delay > 0 && 2 * idx >= wgs_x)
+    for (int i = 0; i < g.delay; i += 1024) __builtin_amdgcn_s_sleep(16);     // s_sleep n = about 64 n cycles
+
+  constexpr int RS = 8;
+  auto setup = [&](int local) {
+    SsTile t;
+    const int tile_lin = t_first + local;
+    const int strip = tile_lin / (RS * tiles_n);
+    const int within = tile_lin - strip * (RS * tiles_n);
+    const int strip_rows = min(RS, tiles_m - strip * RS);
+    t.tile_n = within / strip_rows;
+    t.tile_m = strip * RS + (within - t.tile_n * strip_rows);
+    t.m0 = t.tile_m * BM;
+    t.n0 = t.tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int P = (wave * A_LD + i) * 64 + lane;
+      const int row = P / 6, pos = P - row * 6;
+      const int q = (pos + 3 * ((row >> 3) & 1)) % 6;
+      t.a_voff[i] = t.m0 + row < g.M ? (unsigned)(row * g.lda + q * 16) : kOob;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+      const int P = (wave * B_LD + i) * 64 + lane;
+      const int row = P / 6, pos = P - row * 6;
+      const int q = (pos + 3 * ((row >> 3) & 1)) % 6;
+      t.b_voff[i] = t.n0 + row < g.N ? (unsigned)(row * g.ldb + q * 16) : kOob;
+    }
+    t.soffA0 = t.m0 * g.lda;
+    t.soffB0 = t.n0 * g.ldb;
+    return t;
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // stage s of a tile lives in slot (s + 2) % 3: the epilogue keeps slot 2 free for stage 0 of the next tile
+  auto slot_of = [](int s) { return (s + 2) % NS; };
+  auto dma_item = [&](const SsTile& t, int s, int k, bool live) {
+    char* base = smem + slot_of(s) * SLOT;
+    if (k < A_LD) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, live ? g.a_bytes : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + (wave * A_LD + k) * 1024), 16, (int)t.a_voff[k], t.soffA0 + s * ROWB, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, live ? g.b_bytes : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + A_BYTES + (wave * B_LD + (k - A_LD)) * 1024), 16, (int)t.b_voff[k - A_LD],
+                                               t.soffB0 + s * ROWB, 0, 0);
+    }
+  };
+  int foff[3];
+  {
+    const int b3 = (l31 >> 3) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) foff[p] = 16 * ((3 * half + p + 3 * b3) % 6);
+  }
+  const int a_row = (wm * TM * 32 + l31) * ROWB;
+  const int b_row = A_BYTES + (wn * TN * 32 + l31) * ROWB;
+  u32x4 fa[2][TM][3], fb[2][TN][3];
+  auto read_frags = [&](int s, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    const char* base = smem + slot_of(s) * SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][i][p] = *reinterpret_cast<const u32x4*>(base + a_row + i * 32 * ROWB + foff[p]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[set][j][p] = *reinterpret_cast<const u32x4*>(base + b_row + j * 32 * ROWB + foff[p]);
+    }
+  };
+  f32x16 acc[TM][TN];
+  const int ns = g.K / 16;
+  SsTile cur = setup(idx);
+  auto stage = [&](int s, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPS) : "memory");     // stage s + 1 landed; s + 2 may be in flight
+    __builtin_amdgcn_s_barrier();
+    const bool live = s + 3 < ns;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    int n = 0;
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][i][PA[pr]]),
+                                                               __builtin_bit_cast(bf16x8, fb[set][j][PB[pr]]), acc[i][j], 0, 0, 0);
+          if (n == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(s + 1, std::integral_constant<int, set ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (n % 4 == 3 && n / 4 < LPS) {
+            dma_item(cur, s + 3, n / 4, live);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          ++n;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  float* T = reinterpret_cast<float*>(smem);                                  // [PT_HC][PT_TS]: slots 0 and (part of) 1
+  float* red_cmax = reinterpret_cast<float*>(smem + PT_MISC);                 // [WM][BN]
+  float* red_csum = red_cmax + WM * BN;                                       // [WM][BN]
+  float* red_rm = red_csum + WM * BN;                                         // [2][BM]
+  float* red_rs = red_rm + 2 * BM;                                            // [2][BM]
+  auto vmax = [](float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  };
+  const int rrow = tid & (BM - 1), rsub = tid >> 7;                           // row pass: thread = (row, 32 of the half's 64 columns)
+  constexpr int CPS = PT_HC / 2;
+
+  // prologue of the first tile: three stages in flight
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int k = 0; k < LPS; ++k) dma_item(cur, s, k, s < ns);
+
+  for (int local = idx;;) {
+#ifdef OPP_TUNING
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");            // stage 0 landed (and everything older: the last tile's stores)
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, std::integral_constant<int, 0>{});
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef OPP_TUNING
+    const unsigned long long ts1 = __builtin_readcyclecounter();
+#endif
+    for (int s = 0; s < ns; s += 2) {
+      stage(s, std::integral_constant<int, 0>{});
+      stage(s + 1, std::integral_constant<int, 1>{});
+    }
+#ifdef OPP_TUNING
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    // (thread coordinates re-derived from an opaque copy of the thread index: hoisted out of the tile loop, the epilogue's address
+    // arithmetic would stay live across the K loop -- 120 spilled registers in the first build)
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    const int e_wave = __builtin_amdgcn_readfirstlane(te >> 6);
+    const int e_wm = e_wave / WN, e_wn = e_wave % WN, e_half = (te >> 5) & 1, e_l31 = te & 31;
+    const int e_rrow = te & (BM - 1), e_rsub = te >> 7;
+    if ((g.out_mul != 1.f) || (g.out_div != 1.f)) {
+      const float rd = 1.0f / g.out_div;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = div_invariant(acc[i][j][r] * g.out_mul, g.out_div, rd);
+    }
+    const int m0 = cur.m0, n0 = cur.n0;
+    auto row_of = [&](int i, int r) { return e_wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * e_half; };
+    if (g.row_mask != nullptr) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float mk = g.row_mask[min(m0 + row_of(i, r), g.M - 1)];
+          const float add = mk == 0.f ? -1e9f : 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j][r] += add;
+        }
+    }
+    const int nrows = min(BM, g.M - m0), ncols = min(BN, g.N - n0);
+    const bool full = nrows == BM && ncols == BN;
+    const int next_local = local + wgs_x;
+    const bool has_next = next_local < t_count;
+    SsTile nxt = cur;
+    auto body = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      // columns, from the accumulators: max over this wave's 64 rows, then over the two wave rows (the arithmetic of gemm_ss_kernel)
+      float cmx[TN], csm[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = vmax(m, (FULL || row_of(i, r) < nrows) ? acc[i][j][r] : -INFINITY);
+        m = vmax(m, __shfl_xor(m, 32, 64));
+        if (e_half == 0) red_cmax[e_wm * BN + e_wn * TN * 32 + j * 32 + e_l31] = m;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // the zero-sized tail DMAs and the last fragment reads
+      __syncthreads();                                                         // every slot is dead; the column maxima are visible
+      if (has_next) {                                                          // stage 0 of the next tile -> slot 2, under this epilogue
+        nxt = setup(next_local);
+#pragma unroll
+        for (int k = 0; k < LPS; ++k) dma_item(nxt, 0, k, true);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) cmx[j] = vmax(red_cmax[e_wn * TN * 32 + j * 32 + e_l31], red_cmax[BN + e_wn * TN * 32 + j * 32 + e_l31]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += (FULL || row_of(i, r) < nrows) ? __expf(acc[i][j][r] - cmx[j]) : 0.f;
+        csm[j] = sm + __shfl_xor(sm, 32, 64);
+        if (e_half == 0) red_csum[e_wm * BN + e_wn * TN * 32 + j * 32 + e_l31] = csm[j];
+      }
+      if (e_wm == 0 && e_half == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if (e_wn * TN * 32 + j * 32 + e_l31 < ncols) g.stat_colmax[(size_t)cur.tile_m * g.N + n0 + e_wn * TN * 32 + j * 32 + e_l31] = cmx[j];
+      }
+      // rows: the tile is staged 64 columns at a time; the thread (row, 32 columns) keeps a running (max, sum exp) of its row
+      float RM = -INFINITY, RSUM = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (e_wn == h) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = j * 32 + e_l31, row = e_wm * TM * 32 + i * 32 + 8 * q4 + 4 * e_half;
+                *reinterpret_cast<float4*>(T + col * PT_TS + row) =
+                    make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+              }
+        }
+        __syncthreads();
+        {
+          const int c0 = e_rsub * CPS;
+          float rv[CPS];
+          float m = -INFINITY;
+#pragma unroll
+          for (int c = 0; c < CPS; ++c) {
+            rv[c] = T[(c0 + c) * PT_TS + e_rrow];
+            m = vmax(m, (FULL || h * PT_HC + c0 + c < ncols) ? rv[c] : -INFINITY);
+          }
+          float sacc = 0.f;
+#pragma unroll
+          for (int c = 0; c < CPS; ++c) sacc += (FULL || h * PT_HC + c0 + c < ncols) ? __expf(rv[c] - m) : 0.f;
+          // online merge, fixed order (e_half 0 then e_half 1): exp(-inf - finite) = 0 covers the empty side
+          const float M2 = vmax(RM, m);
+          if (FULL || M2 > -INFINITY) RSUM = RSUM * __expf(RM - M2) + sacc * __expf(m - M2);
+          RM = M2;
+        }
+        // the e_half leaves: lane = 16 bytes of a row of out[col][row] (the launcher takes this kernel for 16-byte aligned outputs only)
+#pragma unroll
+        for (int it = 0; it < PT_HC * (BM / 4) / NT; ++it) {
+          const int u = te + it * NT;
+          const int col = u / (BM / 4), r4 = (u - col * (BM / 4)) * 4;
+          const int gc = h * PT_HC + col;
+          if (FULL || (gc < ncols && r4 + 3 < nrows)) {
+            *reinterpret_cast<float4*>(g.C + (size_t)(n0 + gc) * g.ldc + m0 + r4) = *reinterpret_cast<const float4*>(T + col * PT_TS + r4);
+          } else if (gc < ncols) {
+            for (int e = 0; e < 4; ++e)
+              if (r4 + e < nrows) g.C[(size_t)(n0 + gc) * g.ldc + m0 + r4 + e] = T[col * PT_TS + r4 + e];
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                                       // the staged e_half is consumed
+      }
+      if (has_next) {                                                          // stages 1, 2 of the next tile -> slots 0, 1
+#pragma unroll
+        for (int s = 1; s < NS; ++s)
+#pragma unroll
+          for (int k = 0; k < LPS; ++k) dma_item(nxt, s, k, s < ns);
+      }
+      red_rm[e_rsub * BM + e_rrow] = RM;
+      red_rs[e_rsub * BM + e_rrow] = RSUM;
+      __syncthreads();
+      if (te < BM) {
+        if (te < nrows) {
+          const float ma = red_rm[te], mb = red_rm[BM + te];
+          const float M2 = vmax(ma, mb);
+          const size_t o = (size_t)(m0 + te) * tiles_n + cur.tile_n;
+          g.stat_rowmax[o] = M2;
+          g.stat_rowsum[o] = red_rs[te] * __expf(ma - M2) + red_rs[BM + te] * __expf(mb - M2);
+        }
+      } else if (te - BM < ncols) {
+        const int u = te - BM;
+        g.stat_colsum[(size_t)cur.tile_m * g.N + n0 + u] = red_csum[u] + red_csum[BN + u];
+      }
+    };
+    if (full) body(std::true_type{});
+    else body(std::false_type{});
+#ifdef OPP_TUNING
+    if (g.dbg_ts != nullptr && lane == 0) {
+      unsigned long long* o = g.dbg_ts + ((size_t)(t_first + local) * 4 + wave) * 4;
+      unsigned hw = 0, xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      o[0] = wave == 1 ? (((unsigned long long)xcc << 32) | hw) : ts0;   // wave 1 reports where the workgroup ran instead of its start stamp
+      o[1] = ts1;
+      o[2] = ts2;
+      o[3] = __builtin_readcyclecounter();
+    }
+#endif
+    if (!has_next) break;
+    cur = nxt;
+    local = next_local;
+  }
+}
+
 #ifdef OPP_TUNING
 unsigned long long* g_ss_dbg_ts = nullptr;
 int g_ss_dbg_mode = 0;
 #endif
+
+constexpr int kPersistDelay = 12288;      // cycles the second resident of a CU starts late (about half a tile); OPP_SS_DELAY overrides
+
+// compute units of the current device (cached per device: a process may drive several GPUs)
+int opp_cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cached[dev]) {
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cached[dev] = cus > 0 ? cus : 256;
+  }
+  return cached[dev];
+}
 
 template <int MODE>
 int launch_ss(const OppGemmSS& g, hipStream_t stream, int symbol) {
@@ -597,18 +937,6 @@ int opp_gemm_ss_tile_cols() { return BN; }
 
 int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
   OppGemmSS g = g_in;
-  {
-    static const int prio_env = getenv("OPP_SS_PRIO") ? atoi(getenv("OPP_SS_PRIO")) : 0;
-    g.prio_mode = prio_env;
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    static int cus_cached = 0;
-    if (!cus_cached) {
-      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      cus_cached = cus > 0 ? cus : 256;
-    }
-    g.dephase_blocks = 2 * cus_cached;       // the first generation: two workgroups per CU
-  }
   OPP_CHECK_ARG(g.A && g.B && g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm_ss: bad operands / K %% 32 (M %d N %d K %d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.lda % 16 == 0 && g.ldb % 16 == 0 && g.lda >= g.K * 6 && g.ldb >= g.K * 6, "gemm_ss: operand row strides are bytes, >= 6 K, 16-byte multiples");
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -627,6 +955,21 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
     OPP_CHECK_ARG(g.stat_rowmax && g.stat_rowsum && g.stat_colmax && g.stat_colsum && g.C && g.ldc >= g.M, "gemm_ss: statistics / score outputs missing");
     OPP_CHECK_ARG((size_t)g.N * (size_t)g.ldc < (1ull << 31), "gemm_ss: output too large for 32-bit indexing");
     g.vec_store = (al16(g.C) && g.ldc % 4 == 0) ? 1 : 0;
+    // persistent kernel (two resident workgroups per CU walk static tile lists); OPP_SS_PERSIST=0: one workgroup per tile (A/B switch of the tools)
+    static const int persist_env = getenv("OPP_SS_PERSIST") ? atoi(getenv("OPP_SS_PERSIST")) : 1;
+    static const int delay_env = getenv("OPP_SS_DELAY") ? atoi(getenv("OPP_SS_DELAY")) : kPersistDelay;
+    const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.N, BN);
+    if (persist_env && tiles > 8 && g.vec_store) {
+      const int slots = 2 * opp_cu_count();
+      g.delay = tiles > slots ? delay_env : 0;         // (one tile per workgroup: nothing to de-phase)
+      auto k = gemm_ss_persist_kernel;
+      static OppLdsOnce lds_once;
+      opp_lds_opt_in(reinterpret_cast<const void*>(k), PT_LDS, lds_once);
+      OppProfScope prof(OPP_PROF_SCORE_SS, stream, 2.0 * (double)g.M * (double)g.N * (double)g.K);
+      hipLaunchKernelGGL(k, dim3(tiles < slots ? tiles : slots), dim3(NT), PT_LDS, stream, g);
+      OPP_CHECK_LAUNCH("gemm_ss_persist_kernel");
+      return OPP_OK;
+    }
     return launch_ss<OPP_SS_STATS_STORE>(g, stream, OPP_PROF_SCORE_SS);
   }
   if (g.mode == OPP_SS_CONF) {

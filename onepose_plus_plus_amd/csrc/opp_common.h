@@ -169,6 +169,7 @@ int opp_gemm_launch(const OppGemm& g, hipStream_t stream);
 int opp_gemm_launch_cfg(const OppGemm& g, int cfg, hipStream_t stream);
 // the tile configuration the launcher would pick for g by itself (host only, no launch); + 1000 when a bf16x3 convolution of this shape runs as 4 K slices
 int opp_gemm_choose_tile(const OppGemm& g);
+bool opp_conv_splitk_by_shape(long long M, int n_store, int K);   // gemm_mfma.hip: the launcher's shape rule for 4 K slices
 
 #ifdef __HIPCC__
 // wave64 sum on the DPP path (no LDS round trips): quad butterflies, half-row / row mirrors, then the two

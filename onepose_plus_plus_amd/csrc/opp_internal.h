@@ -148,8 +148,7 @@ struct OppGemmSS {
   int* part_ties = nullptr;
   float* part_rowmax = nullptr;
   int a_bytes = 0, b_bytes = 0, vec_store = 0;   // filled by the launcher
-  int prio_mode = 0;                             // A/B switch OPP_SS_PRIO: 1 / 2 = static s_setprio for every other workgroup of an XCD; >= 3 = de-phasing sleep
-  int dephase_blocks = 0;                        // filled by the launcher: workgroups of the first generation (2 per CU)
+  int delay = 0;                                 // filled by the launcher (persistent kernel): cycles the second resident of a CU starts late
   unsigned long long* dbg_ts = nullptr;          // -DOPP_TUNING builds: 4 shader-clock stamps per wave
 };
 void opp_gemm_ss_debug_timestamps(void* buf, int mode);   // mode 0: both sweeps stamp, else only that OPP_SS_* mode

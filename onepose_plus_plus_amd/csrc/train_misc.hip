@@ -340,8 +340,14 @@ __global__ __launch_bounds__(256) void assign_keys_kernel(const float* __restric
     } else {
       // keypoints2D_coarse_selected / query_img_scale[[1, 0]] * coarse_scale, rounded half to even (:205-212)
       const float x = rintf(kc[2 * kp] / sx * cs), y = rintf(kc[2 * kp + 1] / sy * cs);
-      long long j = (long long)(y * (float)wc + x);   // (:219-223)
-      if (!(j > L)) {                              // invalid_mask = j_ids > conf_matrix.shape[1]  (:225): j == L survives the mask ...
+      const float jf = y * (float)wc + x;
+      // NaN / inf / beyond int64: `.long()` upstream gives INT64_MIN and the indexing raises; here the float -> integer conversion would be
+      // undefined, so such keypoints are reported through the status word (the host raises IndexError) instead of landing in some cell
+      const bool finite = jf == jf && fabsf(jf) < 9.0e18f;
+      long long j = finite ? (long long)jf : 0;      // (:219-223)
+      if (!finite) {
+        atomicOr(status, 1);
+      } else if (!(j > L)) {                              // invalid_mask = j_ids > conf_matrix.shape[1]  (:225): j == L survives the mask ...
         if (j < 0) j += L;
         if (j < 0 || j >= L) atomicOr(status, 1);   // ... and is an IndexError upstream
         else key = i * (long long)L + j;

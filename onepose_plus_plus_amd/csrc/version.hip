@@ -9,6 +9,14 @@
 
 extern "C" const char* opp_source_hash(void) { return OPP_SRC_HASH; }
 
+extern "C" int opp_supports_precision(int p) {
+#ifdef OPP_TUNING
+  return p >= 0 && p <= 3;
+#else
+  return p == 0 || p == 3;      // fp32, bf16x3: the arithmetics not narrower than the reference's fp32
+#endif
+}
+
 // A kernel that does nothing: opp_profile_event_overhead times it exactly like every armed symbol (an event before, an event
 // after, on the launch stream), which measures what the event pair itself adds to a short launch.
 namespace {

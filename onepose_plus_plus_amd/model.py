@@ -143,7 +143,7 @@ def _validate_config(cfg):
         raise NotImplementedError()
 
 
-GEMM_PRECISIONS = {"fp32": 0, "fp16x2": 1, "fp16x2_all": 2, "bf16x3": 3}
+GEMM_PRECISIONS = {"fp32": 0, "bf16x3": 3}        # opp_config.gemm_precision (1 / 2 = fp16x2: tuning library only, not offered here)
 DEFAULT_GEMM_PRECISION = "bf16x3"
 
 
@@ -193,11 +193,8 @@ class OnePosePlus_model(nn.Module):
                         bf16 triples (24 significant bits, fp32 exponent range), six bf16 MFMAs per product --
                         not narrower than the reference's fp32, 2.6x the fp32 MFMA peak
           "fp32"        exact fp32 MFMA (bit-for-bit an fmaf chain)
-          "fp16x2"      opt-in fast mode, NARROWER than fp32: operands as hi + lo fp16 pairs (22-bit mantissas,
-                        fp16 exponent range), three fp16 MFMAs per product; the coarse score GEMM stays fp32.
-                        Range guard: a forward whose activations leave the fp16 range is detected on the device
-                        and re-run in bf16x3, and the module stays in bf16x3 from then on (warning)
-          "fp16x2_all"  as fp16x2, score GEMM included
+        Arithmetics narrower than fp32 (the fp16x2 modes of rounds 1-5) are not part of the product: they live in the tuning
+        library behind the C ABI only.
         See include/opp_hip.h `opp_config.gemm_precision`."""
         if name not in GEMM_PRECISIONS:
             raise ValueError("gemm_precision must be one of %s" % (sorted(GEMM_PRECISIONS),))
@@ -492,14 +489,6 @@ class OnePosePlus_model(nn.Module):
             t = t.float()
         return t.contiguous()
 
-    def _range_fallback(self, data, use_token_cache=True, sample=None):
-        """fp16x2 range guard tripped (include/opp_hip.h `opp_set_status_flag`): this forward and all later ones
-        run in bf16x3, which has the full fp32 exponent range."""
-        warnings.warn("onepose_plus_plus_amd: activations left the fp16 range of gemm_precision %r (or the input is not "
-                      "finite); re-running in 'bf16x3' and keeping that arithmetic" % (self.gemm_precision,))
-        self.set_gemm_precision("bf16x3")          # new C context: _forward_single re-applies the per-sample state
-        return self._forward_single(data, use_token_cache, sample)
-
     def forward(self, data):
         """Same contract as the reference forward (OnePosePlusModel.py:96-201); updates `data`.
         B = 1 without `query_image_mask` (what inference.py runs) takes the fused single-call path; B > 1 and / or a
@@ -606,10 +595,6 @@ class OnePosePlus_model(nn.Module):
         hc, wc, hf, wf = H // 8, W // 8, H // 2, W // 2
         L = hc * wc
         dC, dF = cfg["loftr_coarse"]["d_model"], cfg["loftr_fine"]["d_model"]
-        if self.gemm_precision in ("fp16x2", "fp16x2_all"):
-            # the narrower opt-in fast mode is an inference option: its range guard re-runs a forward, which a training
-            # step (running statistics already updated, random draws consumed) cannot do
-            raise RuntimeError("train() mode runs in 'bf16x3' or 'fp32'; gemm_precision %r is inference-only" % (self.gemm_precision,))
         try:
             with torch.cuda.device(device):
                 self._forward_train_impl(data, cfg, img, device, B, H, W, hc, wc, hf, wf, L, dC, dF, graph)
@@ -784,12 +769,11 @@ class OnePosePlus_model(nn.Module):
         try:
             return self._forward_single_impl(data, use_token_cache, sample)
         finally:
-            # the C context keeps raw pointers to per-call tensors (range-guard flag, query mask, extent reference):
+            # the C context keeps raw pointers to per-call tensors (query mask, extent reference, object prefix, patch buffers):
             # none of them may outlive the call (the tensors are freed / reused by the caching allocator afterwards)
             ctx = self._rt.get("ctx")
             if ctx:
                 lib = _lib.load()
-                lib.opp_set_status_flag(ctx, None)
                 lib.opp_set_query_mask(ctx, None)
                 lib.opp_set_keypoint_extent_ref(ctx, None, 0)
                 lib.opp_set_object_prefix(ctx, None, 0)
@@ -852,9 +836,7 @@ class OnePosePlus_model(nn.Module):
             mconf = torch.empty(N, dtype=torch.float32, device=device)
             mk_c = torch.empty((N, 2), dtype=torch.float32, device=device)
             mk_3d = torch.empty((N, 3), dtype=torch.float32, device=device)
-            count = torch.zeros(2, dtype=torch.int32, device=device)    # [M, fp16x2 range-guard flag]
-            guarded = self.gemm_precision in ("fp16x2", "fp16x2_all")
-            _lib.check(lib.opp_set_status_flag(ctx, count.data_ptr() + 4 if guarded else None), "opp_set_status_flag")
+            count = torch.zeros(1, dtype=torch.int32, device=device)    # M
             ws_bytes = lib.opp_forward_coarse_workspace_bytes(ctx, H, W, N)
             ws = self._workspace(ws_bytes, device)
             scale_c = float(H) / float(hc)                                               # coarse_matching.py:222
@@ -867,9 +849,7 @@ class OnePosePlus_model(nn.Module):
                 mk_c.data_ptr(), mk_3d.data_ptr(), count.data_ptr(), ws.data_ptr(), ws.numel(), stream),
                 "opp_forward_coarse")
             with self.profiler.record_function("LoFTR/coarse-matching/get_coarse_match/argmax-conf"):
-                M, flag = count.tolist()                                                 # the one D2H sync
-            if flag:
-                return self._range_fallback(data, use_token_cache, sample)
+                M = int(count.item())                                                    # the one D2H sync
             self._rt["last_matches"] = M
             b_ids = torch.zeros(M, dtype=torch.int64, device=device)
             data.update({
@@ -901,8 +881,6 @@ class OnePosePlus_model(nn.Module):
                     mk_c.data_ptr(), scale_f, qscale.data_ptr() if qscale is not None else None,
                     1 if cfg["loftr_fine"]["enable"] else 0, expec.data_ptr(), mk_f.data_ptr(), fws.data_ptr(), fws.numel(), stream),
                     "opp_fine_patches")
-                if guarded and int(count[1].item()):
-                    return self._range_fallback(data, use_token_cache, sample)
                 data.update({"expec_f": expec, "mkpts_query_f": mk_f})
                 self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, x1_keep, x2o_keep)
                 return
@@ -918,8 +896,6 @@ class OnePosePlus_model(nn.Module):
                 mk_c.data_ptr(), scale_f, qscale.data_ptr() if qscale is not None else None,
                 1 if cfg["loftr_fine"]["enable"] else 0, expec.data_ptr(), mk_f.data_ptr(), fws.data_ptr(),
                 fws.numel(), stream), "opp_fine")
-            if guarded and int(count[1].item()):       # fine-stage GEMMs (fast mode only: one more sync)
-                return self._range_fallback(data, use_token_cache, sample)
             data.update({"expec_f": expec, "mkpts_query_f": mk_f})
             # keep every tensor whose pointer was handed to the stream alive until here
             self._rt["last"] = (img_c, kpts, bank_f, bank_c, qscale, feat_f, x1_keep, x2o_keep)

@@ -124,7 +124,10 @@ def test_gemm_precision_selector(monkeypatch):
     from onepose_plus_plus_amd import model as M
     m = OnePosePlus_model(default_config())
     assert m.gemm_precision == M.DEFAULT_GEMM_PRECISION == "bf16x3"        # the default is not narrower than fp32
-    assert [m.set_gemm_precision(p)._c_config().gemm_precision for p in ("fp32", "fp16x2", "fp16x2_all", "bf16x3")] == [0, 1, 2, 3]
+    assert [m.set_gemm_precision(p)._c_config().gemm_precision for p in ("fp32", "bf16x3")] == [0, 3]
+    for narrower in ("fp16x2", "fp16x2_all", "bf16"):                      # nothing narrower than fp32 is offered
+        with pytest.raises(ValueError):
+            m.set_gemm_precision(narrower)
     assert pickle.loads(pickle.dumps(m)).gemm_precision == "bf16x3"              # travels to Ray-style workers
     with pytest.raises(ValueError):
         m.set_gemm_precision("bf16")

@@ -17,17 +17,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _line_and_detail(stdout, detail_path):
+    """bench.py's ONE line (<= 6 KB: numbers only) + the sidecar it wrote (per-rank device records, full legs)"""
+    line = [ln for ln in stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(line) < 6000
+    out = json.loads(line)
+    with open(detail_path) as f:
+        out["detail_record"] = json.load(f)
+    return out
+
+
 def _run_bench(extra, env_extra=None):
+    import tempfile
     env = dict(os.environ)
     env.pop("RANK", None)
     env.pop("WORLD_SIZE", None)
     env.update(env_extra or {})
+    env["OPP_BENCH_DETAIL"] = os.path.join(tempfile.mkdtemp(), "bench_detail.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-seconds", "0",
                         "--no-roofline", "--no-legs", "--hw", "128", "--n-points", "300"] + extra,
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    return _line_and_detail(r.stdout, env["OPP_BENCH_DETAIL"])
 
 
 def test_bench_plain_and_torchrun_paths_agree():
@@ -35,16 +46,20 @@ def test_bench_plain_and_torchrun_paths_agree():
     assert plain["n_gpus"] == 1 and plain["config"]["n_ranks_seen"] == 1 and plain["value"] > 0
     # the N > 1 launcher path, exercised with N = 1: RANK / WORLD_SIZE set by torch.distributed.run, RCCL process group
     port = str(29000 + os.getpid() % 2000)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPP_BENCH_PIN="1")     # also exercise the NUMA pinning of the N > 1 path
+    import tempfile
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OPP_BENCH_PIN="1",     # also exercise the NUMA pinning of the N > 1 path
+               OPP_BENCH_DETAIL=os.path.join(tempfile.mkdtemp(), "bench_detail.json"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
                         "--cpu-seconds", "0", "--no-roofline", "--no-legs", "--hw", "128", "--n-points", "300"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    tr = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert tr["config"]["n_ranks_seen"] == 1 and tr["config"]["rank_devices"][0]["rank"] == 0
-    assert tr["value"] > 0 and tr["n_gpus"] == 1 and tr["scaling"] == "weak"
-    assert "host_affinity" in tr["config"]["rank_devices"][0] and tr["config"]["per_rank_images_per_s"]["sum"] > 0
+    tr = _line_and_detail(r.stdout, env["OPP_BENCH_DETAIL"])
+    devs = tr["detail_record"]["config"]["rank_devices"]
+    assert tr["config"]["n_ranks_seen"] == 1 and devs[0]["rank"] == 0
+    assert tr["config"]["ranks"] == [[0, 0, devs[0]["device"], devs[0]["images_per_s"]]]      # [rank, local_rank, device, images/s] on the line
+    assert tr["value"] > 0 and tr["n_gpus"] == 1 and tr["scaling"] == "weak" and tr["value"] == tr["detail_record"]["value"]
+    assert "host_affinity" in devs[0] and tr["config"]["per_rank_images_per_s"]["sum"] > 0
     assert tr["config"]["images_per_step"] == 16 and abs(tr["ms_per_step"] - 16 * tr["ms_per_image"]) < 1e-2 * tr["ms_per_step"]
 
 
@@ -52,8 +67,10 @@ def test_bench_plain_and_torchrun_paths_agree():
 def test_bench_self_launch_two_ranks():
     out = _run_bench(["--gpus", "2"])
     assert out["n_gpus"] == 2 and out["config"]["n_ranks_seen"] == 2
-    devs = sorted(d["device"] for d in out["config"]["rank_devices"])
-    assert devs == [0, 1] and len({d["pid"] for d in out["config"]["rank_devices"]}) == 2
+    recs = out["detail_record"]["config"]["rank_devices"]
+    devs = sorted(d["device"] for d in recs)
+    assert devs == [0, 1] and len({d["pid"] for d in recs}) == 2
+    assert sorted(r[2] for r in out["config"]["ranks"]) == [0, 1]
 
 
 def _nccl_worker(rank, world, port, q):
