@@ -955,8 +955,11 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
     OPP_CHECK_ARG(g.stat_rowmax && g.stat_rowsum && g.stat_colmax && g.stat_colsum && g.C && g.ldc >= g.M, "gemm_ss: statistics / score outputs missing");
     OPP_CHECK_ARG((size_t)g.N * (size_t)g.ldc < (1ull << 31), "gemm_ss: output too large for 32-bit indexing");
     g.vec_store = (al16(g.C) && g.ldc % 4 == 0) ? 1 : 0;
-    // persistent kernel (two resident workgroups per CU walk static tile lists); OPP_SS_PERSIST=0: one workgroup per tile (A/B switch of the tools)
-    static const int persist_env = getenv("OPP_SS_PERSIST") ? atoi(getenv("OPP_SS_PERSIST")) : 1;
+    // persistent kernel (two resident workgroups per CU walk static tile lists): OPP_SS_PERSIST=1.  Measured r06 (profiles/r06_ss_persistent_ab.txt,
+    // r06_ss_timeline.txt): the prologue disappears (6.3 k -> 0.4 k cycles per tile) but the tile costs the same 42-43 k cycles -- the K loops of the
+    // two residents overlap 46-56 % of the time and slow each other down exactly as in the one-tile kernel -- so the matcher is 140 us either way
+    // and the default stays the one-tile kernel
+    static const int persist_env = getenv("OPP_SS_PERSIST") ? atoi(getenv("OPP_SS_PERSIST")) : 0;
     static const int delay_env = getenv("OPP_SS_DELAY") ? atoi(getenv("OPP_SS_DELAY")) : kPersistDelay;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.N, BN);
     if (persist_env && tiles > 8 && g.vec_store) {

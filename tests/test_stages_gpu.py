@@ -223,3 +223,17 @@ def test_two_sweep_matcher_equals_the_materialised_path(n, hw_c, planted, mode):
     assert (ca - cb).abs().max() <= 1e-5 * max(1.0, cb.abs().max().item()), (ca - cb).abs().max()
     assert (a["mconf"] - b["mconf"]).abs().max() <= 1e-5, (a["mconf"] - b["mconf"]).abs().max()
     assert torch.equal(a["mkpts_query_c"], b["mkpts_query_c"]) and torch.equal(a["mkpts_3d_db"], b["mkpts_3d_db"])
+
+
+def test_persistent_score_gemm_meets_the_same_bar():
+    """OPP_SS_PERSIST=1 (gemm_ss.hip: persistent single-sweep score GEMM, opt-in since it measured equal to the one-tile kernel): the same
+    matcher fixtures, tie rules and two-sweep comparison in a process that runs it (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_stages_gpu.py"), "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        "-k", "matcher_vs_golden or exact_ties or two_sweep_matcher"],
+                       env=dict(os.environ, OPP_SS_PERSIST="1"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
