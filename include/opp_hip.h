@@ -416,6 +416,16 @@ int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin, const float* w_pa
                     const float* bias, int cout_pad, int ks, int stride, const float* residual,
                     int res_mode, int act, float* y, int tile_cfg, int prec, const float* h2_scale,
                     void* stream);
+/* The same convolution in the bf16x3 arithmetic with PRE-SPLIT activations (round 6; what the inference backbone chains its layers with --
+ * nn.Conv2d + BatchNorm2d + activation of backbone/resnet.py:10-45, :141-164 -- so that a map is split into bf16 triples once, by the
+ * epilogue that produces it, instead of in the K loop of every tap and column tile that reads it).  A pre-split map holds, per pixel row,
+ * every 8 channels as 48 bytes [hi x8 | mid x8 | lo x8] (bf16; opp_pack_b3 over the fp32 rows gives exactly these bytes), 6 cin_pad bytes
+ * per pixel, 16-byte aligned.  x_split != NULL: the input is read from it when the convolution's K walk has no packed tail (any 1x1; 3x3
+ * over cin % 32 == 0 real channels), else from x (one of the two must serve).  y_split != NULL: the epilogue also writes the output
+ * pre-split (y may then be NULL).  Results are bit-identical to opp_conv2d_nhwc(prec = 2). */
+int opp_conv2d_nhwc_split(const float* x, const void* x_split, int Hin, int Win, int cin, const float* w_packed,
+                          const float* bias, int cout_pad, int ks, int stride, const float* residual, int res_mode,
+                          int act, float* y, void* y_split, int tile_cfg, void* stream);
 int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks,
                          int cout_pad, int cin_pad, float* out, void* stream);
 /* floats per packed weight row of a (cin, ks) convolution */

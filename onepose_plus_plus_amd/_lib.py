@@ -104,6 +104,8 @@ SIGNATURES = {
                          c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "opp_conv2d_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "opp_conv2d_nhwc_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                      c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "opp_conv_packed_k": (c_int, [c_int, c_int]),
     "opp_dual_softmax_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "opp_dual_softmax_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -619,9 +619,36 @@ bool conv_splits_by_shape(const ConvDesc& d, size_t pixels, int prec) {
 
 // pad < 0: "same" padding ks / 2 (every convolution of the reference); pad = 0: a VALID convolution over Bn small patches (match-driven
 // fine branch: the out-of-image taps are explicit zero rows of the patch)
+// Pre-split activations (bf16x3 inference backbone, r06; gemm_mfma.hip "ASP"): a convolution whose K walk has no packed tail (Cin % 32 == 0 real
+// channels, or any 1 x 1) can take its input as the [hi x8 | mid x8 | lo x8] rows its PRODUCER's epilogue wrote (x3; 6 bytes per channel,
+// padded channels are zeros) and skip the operand split in its K loop; y3 != null asks this convolution's epilogue for such rows of its own
+// output (y may then be null).  Same bits as the split done in the K loop: results do not change (tests/test_kernels_gpu.py).
+// OPP_ASP=1 switches the chain on (tests / tools; read once per entry call).  OFF by default: measured r06 (profiles/r06_asp_*.txt) a
+// convolution reading pre-split rows is 3-5 % faster, one WRITING them 3-12 % slower (6 instead of 4 bytes per value, 8-byte stores), and
+// the whole forward loses 3-4 % images/s with the chain on.
+inline bool asp_env_on() {
+  const char* e = getenv("OPP_ASP");
+  return e && e[0] == '1';
+}
+thread_local bool t_asp_on = false;
+struct AspScope {
+  bool prev;
+  AspScope() : prev(t_asp_on) { t_asp_on = asp_env_on(); }
+  explicit AspScope(bool on) : prev(t_asp_on) { t_asp_on = on; }
+  ~AspScope() { t_asp_on = prev; }
+};
+bool conv_takes_split(const ConvDesc& d, int prec) {
+  return t_asp_on && prec == OPP_PREC_BF16X3 && opp_conv_tail_grp(d.cin, d.ks) == 0 && !(t_conv_tail && d.w_tail != nullptr);
+}
+inline size_t split_row_bytes(int c_pad) { return (size_t)c_pad * 6; }
+
 int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, const float* res, int res_mode, int act,
-             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false, int pad = -1, int splitk_force = -1) {
+             float* y, hipStream_t s, int h2, int tile_cfg = -1, int Bn = 1, bool raw = false, int pad = -1, int splitk_force = -1,
+             const void* x3 = nullptr, void* y3 = nullptr) {
   OppGemm g;
+  const bool a_split = x3 != nullptr && !raw && conv_takes_split(d, h2);
+  OPP_CHECK_ARG(a_split || x != nullptr, "conv: no fp32 input for a convolution that cannot take the pre-split one");
+  OPP_CHECK_ARG(y3 == nullptr || h2 == OPP_PREC_BF16X3, "conv: pre-split output is a bf16x3 feature");
   static const bool splitk_on = !(getenv("OPP_CONV_SPLITK") && getenv("OPP_CONV_SPLITK")[0] == '0');   // A/B switch of the tools
   g.splitk_ws = splitk_on ? t_splitk_ws : nullptr;
   g.splitk_ws_floats = g.splitk_ws ? t_splitk_ws_floats : 0;
@@ -633,7 +660,10 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
   // raw = training mode: unfolded weights, no BatchNorm shift (bn_train applies the batch statistics afterwards)
   const float* h2s = raw ? d.h2s_train : d.h2s;
   g.h2_inv = (h2 == OPP_PREC_FP16X2 && h2s) ? h2s + 1 : nullptr;
-  g.A0 = x;
+  g.A0 = a_split ? static_cast<const float*>(x3) : x;
+  g.a_split = a_split ? 1 : 0;
+  g.C3 = y3;
+  g.ld3 = (int)split_row_bytes(d.cout_pad());
   g.Bn = Bn;
   g.Hin = Hin;
   g.Win = Win;
@@ -681,21 +711,31 @@ int run_conv(const float* x, int Hin, int Win, const ConvDesc& d, int stride, co
 }
 
 // BasicBlock.forward (resnet.py:37-45)
+// x3 / tmp3 / y3: the pre-split twins of x / tmp / y (null = not kept).  A map is written in fp32 only where something reads it in fp32
+// (a shortcut, a convolution with a packed K tail, the caller): y = null with y3 set drops the fp32 copy, and tmp is fp32 only when conv2
+// cannot take the split rows.
 int run_block(const float* x, int Hin, int Win, const BlockDesc& b, int stride, float* tmp, float* ds, float* y,
-              hipStream_t s, int h2) {
+              hipStream_t s, int h2, const void* x3 = nullptr, void* tmp3 = nullptr, void* y3 = nullptr) {
   const int Ho = Hin / stride, Wo = Win / stride;
-  OPP_TRY(run_conv(x, Hin, Win, b.conv1, stride, nullptr, OPP_RES_NONE, OPP_ACT_RELU, tmp, s, h2));
+  const bool t_split = tmp3 != nullptr && conv_takes_split(b.conv2, h2);
+  OPP_TRY(run_conv(x, Hin, Win, b.conv1, stride, nullptr, OPP_RES_NONE, OPP_ACT_RELU, t_split ? nullptr : tmp, s, h2, -1, 1, false, -1, -1, x3,
+                   t_split ? tmp3 : nullptr));
   const float* shortcut = x;
   if (b.has_down) {
-    OPP_TRY(run_conv(x, Hin, Win, b.down, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, ds, s, h2));
+    OPP_TRY(run_conv(x, Hin, Win, b.down, stride, nullptr, OPP_RES_NONE, OPP_ACT_NONE, ds, s, h2, -1, 1, false, -1, -1, x3));
     shortcut = ds;
   }
-  return run_conv(tmp, Ho, Wo, b.conv2, 1, shortcut, OPP_RES_DIRECT, OPP_ACT_RELU, y, s, h2);
+  OPP_CHECK_ARG(shortcut != nullptr, "block: the shortcut needs the fp32 input map");
+  return run_conv(t_split ? nullptr : tmp, Ho, Wo, b.conv2, 1, shortcut, OPP_RES_DIRECT, OPP_ACT_RELU, y, s, h2, -1, 1, false, -1, -1,
+                  t_split ? tmp3 : nullptr, y3);
 }
 
 struct BackboneBufs {
   float *col, *x0, *t1, *x1a, *x1, *t2, *ds2, *x2a, *x2, *t3, *ds3, *x3a, *x3, *l2, *u2, *x2o, *l1, *u1;
   float *sk1 = nullptr, *sk2 = nullptr;   // split-K scratch of the two stream branches (they may run concurrently: opp_config.fpn_overlap)
+  // bf16x3: pre-split twins (6 B per channel) of the maps whose consumers can take them (run_conv: conv_takes_split); null otherwise
+  void *x0s = nullptr, *t1s = nullptr, *x1as = nullptr, *x1s = nullptr, *x2s = nullptr, *t3s = nullptr, *x3as = nullptr, *x3s = nullptr, *l2s = nullptr,
+       *u2s = nullptr;
 };
 
 size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) {
@@ -721,6 +761,18 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
   b.u1 = a.f(p2 * c2);
   b.sk1 = a.f(kSplitKScratchFloats);
   b.sk2 = a.f(kSplitKScratchFloats);
+  if (gemm_prec(c->cfg) == OPP_PREC_BF16X3 && asp_env_on()) {
+    b.x0s = a.raw(p2 * split_row_bytes(c1));
+    b.t1s = a.raw(p2 * split_row_bytes(c1));
+    b.x1as = a.raw(p2 * split_row_bytes(c1));
+    b.x1s = a.raw(p2 * split_row_bytes(c1));
+    b.x2s = a.raw(p4 * split_row_bytes(c2));
+    b.t3s = a.raw(p8 * split_row_bytes(c3));
+    b.x3as = a.raw(p8 * split_row_bytes(c3));
+    b.x3s = a.raw(p8 * split_row_bytes(c3));
+    b.l2s = a.raw(p4 * split_row_bytes(c3));
+    b.u2s = a.raw(p4 * split_row_bytes(c3));
+  }
   return a.off;
 }
 
@@ -730,6 +782,7 @@ size_t plan_backbone(const opp_ctx* c, int H, int W, Arena& a, BackboneBufs& b) 
 // x1_ext / x2o_ext: caller-owned buffers that receive x1 / x2_out instead of the workspace (match-driven fine branch).
 int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, float* feat_f, Arena& a, hipStream_t s, int phase = 0,
                   BackboneBufs* bufs = nullptr, float* x1_ext = nullptr, float* x2o_ext = nullptr) {
+  AspScope asp_scope;
   OPP_CHECK_ARG(c && c->packed, "backbone: weights not packed");
   OPP_CHECK_ARG(c->bn_packed, "backbone: weights were packed with scope 1 (training step: no BatchNorm-folded convolutions); repack with opp_set_pack_scope(ctx, 0)");
   OPP_CHECK_ARG(H > 0 && W > 0 && H % 8 == 0 && W % 8 == 0, "backbone: H,W must be multiples of 8 (got %dx%d)", H, W);
@@ -746,13 +799,29 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
   }
   const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8;
   const int hp = gemm_prec(c->cfg);
+  // pre-split twin of a map: kept when one of its consumers takes it (conv_takes_split); the fp32 copy: dropped when all of them do
+  auto twin = [&](void* buf, std::initializer_list<const ConvDesc*> consumers) -> void* {
+    if (buf)
+      for (const ConvDesc* d : consumers)
+        if (conv_takes_split(*d, hp)) return buf;
+    return nullptr;
+  };
+  auto fp32_of = [&](float* buf, void* tw, std::initializer_list<const ConvDesc*> consumers) -> float* {
+    if (!tw) return buf;
+    for (const ConvDesc* d : consumers)
+      if (!conv_takes_split(*d, hp)) return buf;
+    return nullptr;
+  };
+  const BlockDesc* B = c->blocks;
   if (phase == 0 || phase == 1) {
     SplitKScope sk_scope(b.sk1);
     // stem: conv7x7/s2 + BN + ReLU (resnet.py:143): one direct kernel (bf16x3), else im2col + GEMM -- bit-identical
     const char* stem_env = getenv("OPP_STEM_DIRECT");          // A/B switch of the tests / tools
+    void* x0s = nullptr;
     if (opp_stem_direct_ok(c->stem.cout, hp) && pad32(c->stem.cout) == c->stem.cout && !(stem_env && stem_env[0] == '0') &&
         (size_t)H2 * W2 * pad32(c->stem.cout) < (1ull << 31)) {
-      OPP_TRY(opp_stem_direct(image, H, W, c->stem.w, c->stem.bias, b.x0, pad32(c->stem.cout), s));
+      x0s = twin(b.x0s, {&B[0].conv1});
+      OPP_TRY(opp_stem_direct(image, H, W, c->stem.w, c->stem.bias, b.x0, pad32(c->stem.cout), s, x0s, (int)split_row_bytes(pad32(c->stem.cout))));
     } else {
       OPP_TRY(opp_stem_im2col(image, 1, H, W, b.col, s));
       OppGemm g;
@@ -775,25 +844,37 @@ int backbone_impl(opp_ctx* c, const float* image, int H, int W, float* feat_c, f
       g.h2_inv = hp == OPP_PREC_FP16X2 ? c->stem.h2s + 1 : nullptr;
       OPP_TRY(opp_gemm_launch(g, s));
     }
-    OPP_TRY(run_block(b.x0, H2, W2, c->blocks[0], 1, b.t1, nullptr, b.x1a, s, hp));   // layer1 (:144)
-    OPP_TRY(run_block(b.x1a, H2, W2, c->blocks[1], 1, b.t1, nullptr, b.x1, s, hp));
-    OPP_TRY(run_block(b.x1, H2, W2, c->blocks[2], 2, b.t2, b.ds2, b.x2a, s, hp));     // layer2 (:145)
-    OPP_TRY(run_block(b.x2a, H4, W4, c->blocks[3], 1, b.t2, nullptr, b.x2, s, hp));
-    OPP_TRY(run_block(b.x2, H4, W4, c->blocks[4], 2, b.t3, b.ds3, b.x3a, s, hp));     // layer3 (:146)
-    OPP_TRY(run_block(b.x3a, H8, W8, c->blocks[5], 1, b.t3, nullptr, b.x3, s, hp));
+    // (x0, x1a, x3a are shortcuts and x1 / x2 may leave through x1_ext / feed a convolution with a packed K tail: those keep their fp32 copy)
+    void* x1as = twin(b.x1as, {&B[1].conv1});
+    OPP_TRY(run_block(b.x0, H2, W2, B[0], 1, b.t1, nullptr, b.x1a, s, hp, x0s, b.t1s, x1as));   // layer1 (:144)
+    b.x1s = twin(b.x1s, {&B[2].conv1, &B[2].down, &c->l1_out});
+    OPP_TRY(run_block(b.x1a, H2, W2, B[1], 1, b.t1, nullptr, b.x1, s, hp, x1as, b.t1s, b.x1s));
+    OPP_TRY(run_block(b.x1, H2, W2, B[2], 2, b.t2, b.ds2, b.x2a, s, hp, b.x1s));                // layer2 (:145)
+    b.x2s = twin(b.x2s, {&B[4].conv1, &B[4].down, &c->l2_out});
+    OPP_TRY(run_block(b.x2a, H4, W4, B[3], 1, b.t2, nullptr, b.x2, s, hp, nullptr, nullptr, b.x2s));
+    void* x3as = twin(b.x3as, {&B[5].conv1});
+    OPP_TRY(run_block(b.x2, H4, W4, B[4], 2, b.t3, b.ds3, b.x3a, s, hp, b.x2s, b.t3s, x3as));   // layer3 (:146)
+    void* x3s = twin(b.x3s, {&c->l3_out});
+    float* x3f = fp32_of(b.x3, x3s, {&c->l3_out});
+    OPP_TRY(run_block(b.x3a, H8, W8, B[5], 1, b.t3, nullptr, x3f, s, hp, x3as, b.t3s, x3s));
     // FPN (:149-157)
-    OPP_TRY(run_conv(b.x3, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp));
+    OPP_TRY(run_conv(x3f, H8, W8, c->l3_out, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_c, s, hp, -1, 1, false, -1, -1, x3s));
   }
   if (phase == 0 || phase == 2 || phase == 3) {
     SplitKScope sk_scope(b.sk2);
-    OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l2, s, hp));
-    OPP_TRY(run_conv(b.l2, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u2, s, hp));
-    OPP_TRY(run_conv(b.u2, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp));
+    void* l2s = twin(b.l2s, {&c->l2_out2a});
+    float* l2f = fp32_of(b.l2, l2s, {&c->l2_out2a});
+    OPP_TRY(run_conv(b.x2, H4, W4, c->l2_out, 1, feat_c, OPP_RES_BILINEAR2X, OPP_ACT_NONE, l2f, s, hp, -1, 1, false, -1, -1, b.x2s, l2s));
+    void* u2s = twin(b.u2s, {&c->l2_out2b});
+    float* u2f = fp32_of(b.u2, u2s, {&c->l2_out2b});
+    OPP_TRY(run_conv(l2f, H4, W4, c->l2_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, u2f, s, hp, -1, 1, false, -1, -1, l2s, u2s));
+    OPP_TRY(run_conv(u2f, H4, W4, c->l2_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, b.x2o, s, hp, -1, 1, false, -1, -1, u2s));
   }
   if (phase == 0 || phase == 2 || phase == 4) {
     SplitKScope sk_scope(b.sk2);
     static const int l1out_cfg = getenv("OPP_L1OUT_CFG") ? atoi(getenv("OPP_L1OUT_CFG")) : -1;   // A/B switch (tools): tile of the K = 128 lateral
-    OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp, hp == OPP_PREC_BF16X3 ? l1out_cfg : -1));
+    OPP_TRY(run_conv(b.x1, H2, W2, c->l1_out, 1, b.x2o, OPP_RES_BILINEAR2X, OPP_ACT_NONE, b.l1, s, hp, hp == OPP_PREC_BF16X3 ? l1out_cfg : -1, 1, false,
+                     -1, -1, b.x1s));
     OPP_TRY(run_conv(b.l1, H2, W2, c->l1_out2a, 1, nullptr, OPP_RES_NONE, OPP_ACT_LEAKY, b.u1, s, hp));
     OPP_TRY(run_conv(b.u1, H2, W2, c->l1_out2b, 1, nullptr, OPP_RES_NONE, OPP_ACT_NONE, feat_f, s, hp));
   }
@@ -2150,6 +2231,22 @@ extern "C" int opp_conv2d_nhwc(const float* x, int Hin, int Win, int cin, const 
   d.bias = const_cast<float*>(bias);
   d.h2s = const_cast<float*>(h2_scale);
   return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, prec, tile_cfg);
+}
+
+extern "C" int opp_conv2d_nhwc_split(const float* x, const void* x_split, int Hin, int Win, int cin, const float* w_packed, const float* bias,
+                                     int cout_pad, int ks, int stride, const float* residual, int res_mode, int act, float* y, void* y_split,
+                                     int tile_cfg, void* stream) {
+  AspScope asp_scope(true);      // the explicit entry: the caller asked for pre-split rows
+  OPP_CHECK_ARG((x || x_split) && w_packed && (y || y_split), "conv2d_split: null argument");
+  OPP_CHECK_ARG(cin > 0 && cout_pad % 32 == 0, "conv2d_split: cout_pad must be padded to 32");
+  ConvDesc d;
+  d.cin = cin;
+  d.cout = cout_pad;
+  d.ks = ks;
+  d.w = const_cast<float*>(w_packed);
+  d.bias = const_cast<float*>(bias);
+  OPP_CHECK_ARG(x || conv_takes_split(d, OPP_PREC_BF16X3), "conv2d_split: a 3x3 convolution over 32 n + (1..4) channels packs its K tail and needs the fp32 input");
+  return run_conv(x, Hin, Win, d, stride, residual, res_mode, act, y, (hipStream_t)stream, OPP_PREC_BF16X3, tile_cfg, 1, false, -1, -1, x_split, y_split);
 }
 
 extern "C" int opp_pack_conv_weight(const float* w, const float* scale, int cout, int cin, int ks, int cout_pad, int cin_pad,

@@ -48,7 +48,40 @@ namespace {
 // alignment and make the 16 rows of a ds_read_b128 lane group land on 16 distinct 4-bank groups)
 constexpr int lds_stride(int prec) { return prec == OPP_PREC_BF16X3 ? 52 : 36; }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_FP32>
+// bf16x3 split of four consecutive k values: x = hi + mid + lo EXACTLY, hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = bf16(x - hi - mid)
+// (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|, the last residual has <= 8 significant bits).  ONE definition for the K loop (activations split on
+// their way to LDS), for the epilogues that emit activations already split (ASP consumers, r06) and for opp_pack_b3: the same bits everywhere.
+__device__ __forceinline__ void opp_split4_b3(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  auto lvl = [](float a, float b, float& ra, float& rb) -> unsigned {
+    const f32x2 t = {a, b};
+    const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
+    ra = a - __uint_as_float(p << 16);
+    rb = b - __uint_as_float(p & 0xffff0000u);
+    return p;
+  };
+  float r0, r1, r2, r3, s0, s1, s2, s3, u0, u1, u2, u3;
+  const unsigned h01 = lvl(v.x, v.y, r0, r1), h23 = lvl(v.z, v.w, r2, r3);
+  const unsigned m01 = lvl(r0, r1, s0, s1), m23 = lvl(r2, r3, s2, s3);
+  const unsigned l01 = lvl(s0, s1, u0, u1), l23 = lvl(s2, s3, u2, u3);
+  hi = make_uint2(h01, h23);
+  mid = make_uint2(m01, m23);
+  lo = make_uint2(l01, l23);
+}
+// four consecutive channels (col % 4 == 0) of a pixel row in the pre-split activation layout: every 8 channels = 48 B [hi x8 | mid x8 | lo x8]
+__device__ __forceinline__ void opp_store_split4(void* base, size_t row_bytes_off, int col, const float4 v) {
+  uint2 hi, mid, lo;
+  opp_split4_b3(v, hi, mid, lo);
+  char* p = static_cast<char*>(base) + row_bytes_off + (col >> 3) * 48 + (col & 7) * 2;
+  *reinterpret_cast<uint2*>(p) = hi;
+  *reinterpret_cast<uint2*>(p + 16) = mid;
+  *reinterpret_cast<uint2*>(p + 32) = lo;
+}
+
+// ASP (r06, bf16x3 convolutions over Cin % 32 == 0): the activation operand arrives PRE-SPLIT in memory (the layout above, written by the
+// producing layer's epilogue), is loaded in 16-byte pieces exactly like the weight rows and goes to LDS with one ds_write_b128 per piece --
+// no split arithmetic in the K loop (it was redone for every tap of a 3 x 3 window and every column tile: ~120 of the ~190 VALU instructions
+// per 32-k chunk and wave, profiles/r06_pmc_conv_*.txt) and no 8-byte LDS stores (a quarter of the LDS cycles were their bank conflicts).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_FP32, bool ASP = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
   constexpr bool H2 = PREC == OPP_PREC_FP16X2;   // operands as hi+lo fp16 pairs, 3 fp16 MFMA products
   constexpr bool H3 = PREC == OPP_PREC_BF16X3;   // operands as hi+mid+lo bf16 triples (exact), 6 bf16 MFMA products
@@ -58,7 +91,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   constexpr int NT32 = BN / 32;                               // 32-column sub-tiles per block
   constexpr int TN = (NT32 + WAVES_N - 1) / WAVES_N;          // per wave (last wave may own fewer)
   constexpr bool kRagged = (NT32 % WAVES_N) != 0;             // e.g. 224 columns on 2 waves = 4 + 3
-  constexpr int A_LD = BM * 8 / NT;
+  static_assert(!ASP || (CONV && PREC == OPP_PREC_BF16X3 && (ABL == 0 || ABL >= 200)), "pre-split activations: bf16x3 convolutions only");
+  // tuning builds, timing only: 91..94 remove one part of the K loop; 200 + mask removes several (bit 0 the global prefetch, 1 the LDS hand-over,
+  // 2 the barrier, 3 the fragment reads) -- 215 is the bare MFMA sequence, the parts come back one at a time (tools/r06_abl2.sh)
+  constexpr int kAblMask = ABL >= 200 ? ABL - 200 : 0;
+  constexpr bool kNoGload = ABL == 91 || (kAblMask & 1), kNoLdsSt = ABL == 92 || (kAblMask & 2), kNoBar = ABL == 93 || (kAblMask & 4),
+                 kNoFrag = ABL == 94 || (kAblMask & 8);
+  constexpr int A_LD = ASP ? (BM * 12 + NT - 1) / NT : BM * 8 / NT;   // ASP: 192 B per row and chunk, 16-byte pieces like the weights
+  constexpr bool kAFrac = ASP && (BM * 12) % NT != 0;                 // (64-row tile on 8 waves: 1.5 pieces per thread)
   // 224-column ring tile: weight rows >= 208 are never real (the tile serves N <= 208, i.e. the 196-channel layers; the launcher checks) --
   // their LDS rows are zeroed once and the loader covers 208 rows = 4.9 pieces per thread instead of 5.25 (one prefetch register set less)
   constexpr int kBRowsLoad = (H3 && BN == 224) ? 208 : BN;
@@ -73,6 +113,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   constexpr bool kRing = H3 && kRagged;
   static_assert(BM % (WAVES_M * 32) == 0 && BN % 32 == 0, "tile shape");
   static_assert((BM * 8) % NT == 0 && (H3 ? (BN * 12) % NT == 0 || BN == 192 || BN == 224 : (BN * 8) % NT == 0), "load split");
+  static_assert(!ASP || !((H3 && ((BN + 31) / 32 % WAVES_N) != 0)), "pre-split activations are not built for the ring tile");
 
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (ABL == 9 || ABL > 90) ts0 = __builtin_readcyclecounter();
@@ -118,9 +159,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // byte offset of each load slot's row start (+ this thread's float4); kOob for rows >= M.
   // conv mode: a_mask bit t = tap t of the window falls OUTSIDE the image for this output pixel.
   unsigned a_base0[A_LD], a_base1[A_LD], a_mask[A_LD];
+  int a_lds[ASP ? A_LD : 1];      // ASP: LDS float offset of the slot's piece inside the A tile
 #pragma unroll
   for (int i = 0; i < A_LD; ++i) {
-    const int r = m0 + lrow + i * (NT / 8);
+    // ASP: slot u = tid + i NT -> (tile row u / 12, 16-byte piece u % 12); else (row lrow + i NT / 8, float4 kq)
+    const int au = tid + i * NT;
+    const int arow = ASP ? au / 12 : lrow + i * (NT / 8);
+    const int apiece = ASP ? au - arow * 12 : 0;
+    if constexpr (ASP) a_lds[i] = arow * kLdsStride + apiece * 4;
+    const int r = m0 + arow;
     if (CONV) {
       const int ox = r % g.Wout;
       const int t = r / g.Wout;
@@ -128,7 +175,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
       const int b = t / g.Hout;
       const int iy0 = oy * g.stride - g.pad;
       const int ix0 = ox * g.stride - g.pad;
-      a_base0[i] = (unsigned)(((b * g.Hin + iy0) * g.Win + ix0) * g.Cin + kq * 4) * 4u;
+      if constexpr (ASP) a_base0[i] = (unsigned)(((b * g.Hin + iy0) * g.Win + ix0) * g.Cin) * 6u + (unsigned)apiece * 16u;
+      else a_base0[i] = (unsigned)(((b * g.Hin + iy0) * g.Win + ix0) * g.Cin + kq * 4) * 4u;
       a_base1[i] = 0;
       unsigned m = 0;
 #pragma unroll
@@ -139,7 +187,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
                           (unsigned)(ix0 + kx) < (unsigned)g.Win;
           m |= (ok ? 1u : 0u) << (ky * g.ksize + kx);
         }
-      a_mask[i] = r < g.M ? ~m : 0xffffffffu;   // bit t set = tap t must read zeros
+      a_mask[i] = (r < g.M && (!kAFrac || au < BM * 12)) ? ~m : 0xffffffffu;   // bit t set = tap t must read zeros
     } else {
       a_base0[i] = r < g.M ? (unsigned)(r * g.lda0 + kq * 4) * 4u : kOob;
       a_base1[i] = r < g.M ? (unsigned)(r * g.lda1 + kq * 4) * 4u : kOob;
@@ -231,7 +279,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
         ++tail_i;
       }
       if (tail_i < 0) {
-        eff_delta = (unsigned)((cur_ky * g.Win + cur_kx) * g.Cin + cur_grp * 32) * 4u;
+        eff_delta = (unsigned)((cur_ky * g.Win + cur_kx) * g.Cin + cur_grp * 32) * (ASP ? 6u : 4u);
         eff_sh = (unsigned)(31 - cur_tap);
       } else {
         tail_lane(tail_i & 1, eff_delta, eff_sh);     // chunks past the end are killed by cur_past
@@ -313,24 +361,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   // bf16x3 mode (H3): x = hi + mid + lo EXACTLY, hi = bf16_rne(x), mid = bf16_rne(x - hi), lo = bf16(x - hi - mid)
   // (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|, the last residual has <= 8 significant bits).  A 32-k chunk of a row is
   // 192 B: four groups of 8 k, each [hi x8 | mid x8 | lo x8].  v_cvt_pk_bf16_f32 + shift/mask + subtract per level.
-  auto split_b3 = [](const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-    auto lvl = [](float a, float b, float& ra, float& rb) -> unsigned {
-      const f32x2 t = {a, b};
-      const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(t, bf16x2));
-      ra = a - __uint_as_float(p << 16);
-      rb = b - __uint_as_float(p & 0xffff0000u);
-      return p;
-    };
-    float r0, r1, r2, r3, s0, s1, s2, s3, u0, u1, u2, u3;
-    const unsigned h01 = lvl(v.x, v.y, r0, r1), h23 = lvl(v.z, v.w, r2, r3);
-    const unsigned m01 = lvl(r0, r1, s0, s1), m23 = lvl(r2, r3, s2, s3);
-    const unsigned l01 = lvl(s0, s1, u0, u1), l23 = lvl(s2, s3, u2, u3);
-    hi = make_uint2(h01, h23);
-    mid = make_uint2(m01, m23);
-    lo = make_uint2(l01, l23);
-  };
+  auto split_b3 = [](const float4 v, uint2& hi, uint2& mid, uint2& lo) { opp_split4_b3(v, hi, mid, lo); };
   auto store_item = [&](int i, int buf, const float4 (&a_reg)[A_LD], const float4 (&b_reg)[B_LD]) {
     if (i < A_LD) {
+      if constexpr (ASP) {           // already split: the piece goes to LDS as it is
+        if (!kAFrac || tid + i * NT < BM * 12) *reinterpret_cast<float4*>(As + buf * BM * kLdsStride + a_lds[i]) = a_reg[i];
+        return;
+      }
       float* row = As + buf * BM * kLdsStride + (lrow + i * (NT / 8)) * kLdsStride;
       if (H3) {
         uint2 hi, mid, lo;
@@ -566,25 +603,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     __builtin_amdgcn_sched_barrier(0);
     mfma_h2(fa[0], fa[1], fb[0], fb[1], true, true, [&](int n) {      // step 0 + prefetch of chunk c+DEPTH
       if (n % kStrideL == 0 && n / kStrideL < kItems) {
-        if (ABL != 91) load_item(n / kStrideL, ga[P], gb[P]);
+        if (!kNoGload) load_item(n / kStrideL, ga[P], gb[P]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
     for (int i = kSlotsL / kStrideL; i < kItems; ++i)
-      if (ABL != 91) load_item(i, ga[P], gb[P]);
+      if (!kNoGload) load_item(i, ga[P], gb[P]);
     __builtin_amdgcn_sched_barrier(0);
     mfma_h2(fa[2], fa[3], fb[2], fb[3], true, false, [&](int n) {     // step 1 cross terms + LDS hand-over
       if (n % kStrideS == 0 && n / kStrideS < kItems) {
-        if (ABL != 92) store_item(n / kStrideS, B1, ga[PN], gb[PN]);
+        if (!kNoLdsSt) store_item(n / kStrideS, B1, ga[PN], gb[PN]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
     for (int i = kSlotsS / kStrideS; i < kItems; ++i)
-      if (ABL != 92) store_item(i, B1, ga[PN], gb[PN]);
+      if (!kNoLdsSt) store_item(i, B1, ga[PN], gb[PN]);
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL != 93) __syncthreads();
+    if (!kNoBar) __syncthreads();
     read_frags(B1, 0, fa[0], fb[0]);
     read_frags(B1, 1, fa[1], fb[1]);
     __builtin_amdgcn_sched_barrier(0);
@@ -625,7 +662,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     constexpr int PN = (P + 1) % DEPTH;
     const int B0 = lb, B1 = lb ^ 1;
     advance();
-    if (ABL != 94) {
+    if (!kNoFrag) {
       read_frags(B0, 3, fa[kH6], fb[kH6]);
       read_frags(B0, 4, fa[kH6 ? 4 : 0], fb[kH6 ? 4 : 0]);
       read_frags(B0, 5, fa[kH6 ? 5 : 0], fb[kH6 ? 5 : 0]);
@@ -633,26 +670,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
     __builtin_amdgcn_sched_barrier(0);
     mfma_b3(0, 0, 6, [&](int n) {                    // step 0 + prefetch of chunk c+DEPTH, one load per slot
       if (n % kStride3L == 0 && n / kStride3L < kItems) {
-        if (ABL != 91) load_item(n / kStride3L, ga[P], gb[P]);
+        if (!kNoGload) load_item(n / kStride3L, ga[P], gb[P]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
     for (int i = kSlots3L / kStride3L; i < kItems; ++i)
-      if (ABL != 91) load_item(i, ga[P], gb[P]);
+      if (!kNoGload) load_item(i, ga[P], gb[P]);
     __builtin_amdgcn_sched_barrier(0);
     mfma_b3(1, 0, 4, [&](int n) {                    // step 1, first four products + LDS hand-over of chunk c+1
       if (n % kStride3S == 0 && n / kStride3S < kItems) {
-        if (ABL != 92) store_item(n / kStride3S, B1, ga[PN], gb[PN]);
+        if (!kNoLdsSt) store_item(n / kStride3S, B1, ga[PN], gb[PN]);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
 #pragma unroll
     for (int i = kSlots3S / kStride3S; i < kItems; ++i)
-      if (ABL != 92) store_item(i, B1, ga[PN], gb[PN]);
+      if (!kNoLdsSt) store_item(i, B1, ga[PN], gb[PN]);
     __builtin_amdgcn_sched_barrier(0);
-    if (ABL != 93) __syncthreads();
-    if (ABL != 94) {
+    if (!kNoBar) __syncthreads();
+    if (!kNoFrag) {
       read_frags(B1, 0, fa[0], fb[0]);
       read_frags(B1, 1, fa[1], fb[1]);
       read_frags(B1, 2, fa[kH6 ? 2 : 0], fb[kH6 ? 2 : 0]);
@@ -1147,6 +1184,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
           for (int e = 0; e < 4; ++e) v[e] *= rm;
         }
       }
+      if constexpr (H3) {    // the same values once more, pre-split for the convolutions that consume this map (launcher: vec_ok, no K slices)
+        if (g.C3 != nullptr) opp_store_split4(g.C3, (size_t)row * g.ld3, col, make_float4(v[0], v[1], v[2], v[3]));
+      }
+      if (g.C == nullptr) continue;       // split output only
       float* cp = g.C + (size_t)row * g.ldc + col + (g.k_splits > 1 ? (size_t)blockIdx.y * g.split_stride : 0);
       if (vec_ok) {
         *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -1168,7 +1209,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
 // the unsplit kernel fuses (folded-BN bias, same-shape residual, ReLU / LeakyReLU); float4 granularity over [M][ld]
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __restrict__ part, int splits, size_t stride4, size_t n4, int ld4,
                                                               const float4* __restrict__ bias, const float4* __restrict__ R, int act,
-                                                              float4* __restrict__ out) {
+                                                              float4* __restrict__ out, void* __restrict__ out3, int ld3) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float4 a = part[i];
     for (int s = 1; s < splits; ++s) {
@@ -1200,7 +1241,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __re
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
     }
-    out[i] = make_float4(v[0], v[1], v[2], v[3]);
+    if (out3 != nullptr) {           // pre-split copy for the consuming convolution (row = i / ld4, channels 4 (i % ld4) ..)
+      const size_t row = i / (size_t)ld4;
+      opp_store_split4(out3, row * (size_t)ld3, (int)(i - row * (size_t)ld4) * 4, make_float4(v[0], v[1], v[2], v[3]));
+    }
+    if (out != nullptr) out[i] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -1228,7 +1273,18 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
   if constexpr (ok) {
     const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float) + extra_lds;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN);
-    if (g.conv) {
+    constexpr bool kAspBuilt = PREC == OPP_PREC_BF16X3 && DEPTH == 2 && !kNarrowB3 && (NT == 512 || (BM == 64 && BN == 64));
+    if (g.conv && g.a_split) {
+      if constexpr (kAspBuilt) {
+        auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, PREC, true>;
+        static OppLdsOnce attr_done;
+        set_lds_once(k, lds, attr_done);
+        hipLaunchKernelGGL(k, dim3(tiles, g.k_splits > 1 ? g.k_splits : 1), dim3(NT), lds, stream, g);
+      } else {
+        opp_set_error("gemm: tile %dx%d is not built for pre-split activations", BM, BN);
+        return OPP_ERR_UNSUPPORTED;
+      }
+    } else if (g.conv) {
       auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, PREC>;
       static OppLdsOnce attr_done;
       set_lds_once(k, lds, attr_done);
@@ -1269,12 +1325,16 @@ int launch_cfg(const OppGemm& g, hipStream_t stream) {
 #ifdef OPP_TUNING
 unsigned long long* g_dbg_ts = nullptr;   // opp_debug_timestamps()
 
-template <int BM, int BN, int WM, int WN, int PREC, int ABL = 9>
+template <int BM, int BN, int WM, int WN, int PREC, int ABL = 9, bool ASP = false>
 int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // conv kernel with phase time stamps
   OppGemm g = g_in;
   g.dbg_ts = g_dbg_ts;
+  if (ASP != (g.a_split != 0)) {
+    opp_set_error("gemm: tuning config and activation layout do not match");
+    return OPP_ERR_INVALID;
+  }
   const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float);
-  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, PREC>;
+  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, PREC, ASP>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN)), dim3(WM * WN * 64), lds, stream, g);
   OPP_CHECK_LAUNCH("opp_gemm_kernel(timed)");
@@ -1308,6 +1368,21 @@ int launch_tuning_cfg(const OppGemm& g, int cfg, hipStream_t stream) {
     case 393: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
     case 394: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 94>(g, stream) : OPP_ERR_INVALID;   // no LDS fragment reads
     case 395: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 95>(g, stream) : OPP_ERR_INVALID;   // no split arithmetic
+    // 256 x 128, several parts removed at once (400 + mask: fp32 rows split in the K loop; 500 + mask: pre-split rows)
+    case 400: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 200>(g, stream) : OPP_ERR_INVALID;
+    case 401: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 201>(g, stream) : OPP_ERR_INVALID;
+    case 403: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 203>(g, stream) : OPP_ERR_INVALID;
+    case 407: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 207>(g, stream) : OPP_ERR_INVALID;
+    case 415: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 215>(g, stream) : OPP_ERR_INVALID;
+    case 411: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 211>(g, stream) : OPP_ERR_INVALID;
+    case 500: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 200, true>(g, stream) : OPP_ERR_INVALID;
+    case 501: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 201, true>(g, stream) : OPP_ERR_INVALID;
+    case 503: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 203, true>(g, stream) : OPP_ERR_INVALID;
+    case 504: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 204, true>(g, stream) : OPP_ERR_INVALID;
+    case 507: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 207, true>(g, stream) : OPP_ERR_INVALID;
+    case 508: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 208, true>(g, stream) : OPP_ERR_INVALID;
+    case 511: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 211, true>(g, stream) : OPP_ERR_INVALID;
+    case 515: return (g.conv && h3) ? launch_timed<256, 128, 4, 2, OPP_PREC_BF16X3, 215, true>(g, stream) : OPP_ERR_INVALID;
     case 191: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 91>(g, stream) : OPP_ERR_INVALID;   // no global loads
     case 192: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 92>(g, stream) : OPP_ERR_INVALID;   // no LDS stores
     case 193: return (g.conv && h2) ? launch_timed<256, 128, 4, 2, OPP_PREC_FP16X2, 93>(g, stream) : OPP_ERR_INVALID;   // no barrier
@@ -1402,6 +1477,7 @@ static int choose_tile(const OppGemm& g) {
       // it LOSES 1-2 % even on the big grid -- the chip is power-limited there, the eighth sub-tile of 128 x 256 multiplies zeros (cheap in
       // energy, only costly in time) while the ring tile moves 25 % more fragment bytes per useful MFMA.  So: latency policy, grids of at
       // least one full round (OPP_TILE_224=0 never, =2 always: the A/B switch of the tools).
+      if (c.bn == 224 && g.a_split) continue;          // the ring tile is not built for pre-split activations
       if (c.bn == 224 && (g.n_store != 224 || g.n_real <= 0 || g.n_real > 208 || on224_env == 0 ||
                           (on224_env != 2 && (g.tile_policy == OPP_TILES_THROUGHPUT || opp_cdiv(g.M, 128) < 256)))) continue;
       const long long tiles = (long long)opp_cdiv(g.M, c.bm) * opp_cdiv(g.n_store, c.bn);
@@ -1427,9 +1503,10 @@ static int choose_tile(const OppGemm& g) {
 
 int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   OppGemm g = g_in;
+  auto al16p = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    bool v = g.n_store % 4 == 0 && g.ldc % 4 == 0 && al16(g.C) && (!g.bias || al16(g.bias)) && g.qk_cols % 4 == 0;
+    bool v = g.n_store % 4 == 0 && (g.C == nullptr || (g.ldc % 4 == 0 && al16(g.C))) && (!g.bias || al16(g.bias)) && g.qk_cols % 4 == 0;
     if (g.res_mode != OPP_RES_NONE) v = v && g.ldr % 4 == 0 && al16(g.R);
     g.vec_epilogue = v ? 1 : 0;
   }
@@ -1445,8 +1522,15 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
   }
   const bool split = g.prec != OPP_PREC_FP32;
   OPP_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm: bad M/N/K (%d,%d,%d)", g.M, g.N, g.K);
-  OPP_CHECK_ARG(g.n_store >= g.N && g.C && g.W && g.A0, "gemm: bad output/operands");
+  OPP_CHECK_ARG(g.n_store >= g.N && (g.C || g.C3) && g.W && g.A0, "gemm: bad output/operands");
   OPP_CHECK_ARG((size_t)g.M * (size_t)g.ldc < (1ull << 31), "gemm: output too large for 32-bit indexing");
+  if (g.C3 != nullptr || g.a_split) {
+    OPP_CHECK_ARG(g.conv && g.prec == OPP_PREC_BF16X3, "gemm: pre-split activations are a bf16x3 convolution feature");
+    OPP_CHECK_ARG(g.C3 == nullptr || (g.vec_epilogue && g.n_store % 8 == 0 && g.ld3 >= g.n_store * 6 && g.ld3 % 16 == 0 && al16p(g.C3) && !g.ln_gamma && !g.stat_rowmax &&
+                                      g.k_splits <= 1), "gemm: split output needs the 16-byte epilogue, whole 8-channel groups and a plain launch");
+    OPP_CHECK_ARG(!g.a_split || (g.tail_grp == 0 && al16p(g.A0)), "gemm: pre-split input needs Cin %% 32 == 0 real channels");
+    OPP_CHECK_ARG(g.C != nullptr || g.C3 != nullptr, "gemm: no output");
+  }
   g.w_bytes = (unsigned)((size_t)g.N * g.ldw * 4);
   OPP_CHECK_ARG((size_t)g.N * g.ldw * 4 < (1ull << 31), "gemm: weight operand too large for buffer addressing");
   OPP_CHECK_ARG(g.prec != OPP_PREC_BF16X3 || g.ldw * 2 >= g.K * 3, "gemm: bf16x3 weights need a row stride of 1.5 K floats");
@@ -1455,7 +1539,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     OPP_CHECK_ARG(g.Cin % 32 == 0 && g.K == k_expect, "conv: Cin %% 32 / K mismatch");
     OPP_CHECK_ARG(g.tail_grp == 0 || (g.ksize == 3 && g.tail_grp == g.Cin / 32 - 1), "conv: K tail packing needs a 3x3 kernel and one partial channel group");
     OPP_CHECK_ARG(g.M == g.Bn * g.Hout * g.Wout, "conv: M != B*Hout*Wout");
-    const size_t ab = (size_t)g.Bn * g.Hin * g.Win * g.Cin * 4;
+    const size_t ab = (size_t)g.Bn * g.Hin * g.Win * g.Cin * (g.a_split ? 6 : 4);
     OPP_CHECK_ARG(ab < (1ull << 31), "conv: input too large for buffer addressing");
     g.a0_bytes = (unsigned)ab;
   } else {
@@ -1485,6 +1569,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     if ((g.splitk_force > 0 || (g.splitk_force < 0 && by_shape)) && nkc >= kSplits && g.splitk_ws_floats >= need && need < (1ull << 31)) {
       OppGemm gs = g;
       gs.C = g.splitk_ws;
+      gs.C3 = nullptr;              // the K slices are fp32 partials; the fixed-order epilogue below emits the split copy
       gs.k_splits = kSplits;
       gs.k_chunks_per_split = opp_cdiv(nkc, kSplits);
       gs.split_stride = (size_t)g.M * g.ldc;
@@ -1500,7 +1585,7 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
       OppProfScope prof_epi(OPP_PROF_SPLITK_EPILOGUE, stream, (double)(kSplits + 1 + (g.res_mode == OPP_RES_DIRECT ? 1 : 0)) * (double)g.M * g.ldc * 4.0);
       hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(g.splitk_ws), kSplits, n4, n4, g.ldc / 4,
                          reinterpret_cast<const float4*>(g.bias), g.res_mode == OPP_RES_DIRECT ? reinterpret_cast<const float4*>(g.R) : nullptr, g.act,
-                         reinterpret_cast<float4*>(g.C));
+                         reinterpret_cast<float4*>(g.C), g.C3, g.ld3);
       OPP_CHECK_LAUNCH("splitk_epilogue_kernel");
       return OPP_OK;
     }

@@ -958,7 +958,8 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
     // persistent kernel (two resident workgroups per CU walk static tile lists): OPP_SS_PERSIST=1.  Measured r06 (profiles/r06_ss_persistent_ab.txt,
     // r06_ss_timeline.txt): the prologue disappears (6.3 k -> 0.4 k cycles per tile) but the tile costs the same 42-43 k cycles -- the K loops of the
     // two residents overlap 46-56 % of the time and slow each other down exactly as in the one-tile kernel -- so the matcher is 140 us either way
-    // and the default stays the one-tile kernel
+    // and the default stays the one-tile kernel.  (Static wave priorities for the K loops -- a loop outranks the partner's epilogue, the second
+    // resident's loop outranks the first's -- were tried on top, profiles/r06_ss_prio_ab.txt: 142-148 us, no better; removed.)
     static const int persist_env = getenv("OPP_SS_PERSIST") ? atoi(getenv("OPP_SS_PERSIST")) : 0;
     static const int delay_env = getenv("OPP_SS_DELAY") ? atoi(getenv("OPP_SS_DELAY")) : kPersistDelay;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.N, BN);

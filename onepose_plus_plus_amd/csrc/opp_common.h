@@ -98,6 +98,11 @@ struct OppGemm {
   // output
   float* C = nullptr;
   int ldc = 0;
+  // bf16x3 convolutions (r06): C3 != null -- the epilogue also writes the output PRE-SPLIT (every 8 channels = 48 B [hi x8 | mid x8 | lo x8],
+  // row stride ld3 BYTES) for the convolutions that consume it; C may then be null (no fp32 copy).  a_split: A0 is such a buffer.
+  void* C3 = nullptr;
+  int ld3 = 0;
+  int a_split = 0;
   int n_store = 0;  // columns [0, n_store) are written (n_store >= N pads with act(0))
   int n_real = 0;   // > 0: weight rows >= n_real are known to be zero padding (channel counts padded to 32); lets the 128 x 224 tile skip rows >= 208
   const float* bias = nullptr;  // [n_store] or null

@@ -168,7 +168,9 @@ int opp_linattn_train_bwd(const float* q, const float* k, const float* v, const 
                           size_t ws_bytes, hipStream_t stream);
 // stem_direct.hip -- 7x7 / stride 2 stem + bias + ReLU without the im2col matrix (bf16x3, 128 output channels)
 bool opp_stem_direct_ok(int cout, int prec);
-int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream);
+// out3 != null: the same map once more in the pre-split activation layout (48 B per 8 channels, row stride ld3 bytes; OppGemm::C3)
+int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream, void* out3 = nullptr,
+                    int ld3 = 0);
 // conv_tail.hip -- the last (cout mod 32 <= 4) output columns of a convolution as fp32 FMA chains (the 196-channel layers: 192 columns on the
 // MFMA kernel + 4 here instead of 224 / 256 padded MFMA columns)
 size_t opp_conv_tail_weight_floats(int cin_pad, int ks);

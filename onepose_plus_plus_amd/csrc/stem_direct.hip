@@ -20,7 +20,7 @@ static_assert(ROWS * CS * 4 >= ROWS * SA, "the output tile reuses the operand sp
 
 __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restrict__ img, int H, int W, int Ho, int Wo,
                                                           const char* __restrict__ wsplit, const float* __restrict__ bias,
-                                                          float* __restrict__ out, int ldc) {
+                                                          float* __restrict__ out, int ldc, char* __restrict__ out3, int ld3) {
   // operand rows [128][400 B]; after the MFMAs the same space stages the output tile [128][CS floats] for 512-byte row stores
   __shared__ __attribute__((aligned(16))) char A[ROWS * CS * 4];
   __shared__ float patch[PH * PWS];
@@ -107,14 +107,30 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restric
       }
   }
   __syncthreads();
+  // eight channels per lane: 32 B of the fp32 row and, for the convolutions that take their input pre-split (gemm_mfma.hip, ASP), the
+  // same eight values as one 48-byte [hi x8 | mid x8 | lo x8] group of the split row (row stride ld3 bytes)
 #pragma unroll
-  for (int it = 0; it < ROWS * (COUT / 4) / 256; ++it) {
+  for (int it = 0; it < ROWS * (COUT / 8) / 256; ++it) {
     const int u = tid + it * 256;
-    const int lr = u / (COUT / 4), c4 = (u - lr * (COUT / 4)) * 4;
+    const int lr = u / (COUT / 8), c8 = (u - lr * (COUT / 8)) * 8;
     const int ly = lr / TX, lx = lr - ly * TX;
     const int oy = oy0 + ly, ox = ox0 + lx;
-    if (oy < Ho && ox < Wo)
-      *reinterpret_cast<float4*>(out + ((size_t)oy * Wo + ox) * ldc + c4) = *reinterpret_cast<const float4*>(Ct + lr * CS + c4);
+    if (oy < Ho && ox < Wo) {
+      const float4 v0 = *reinterpret_cast<const float4*>(Ct + lr * CS + c8), v1 = *reinterpret_cast<const float4*>(Ct + lr * CS + c8 + 4);
+      const size_t pix = (size_t)oy * Wo + ox;
+      if (out != nullptr) {
+        *reinterpret_cast<float4*>(out + pix * ldc + c8) = v0;
+        *reinterpret_cast<float4*>(out + pix * ldc + c8 + 4) = v1;
+      }
+      if (out3 != nullptr) {
+        u32x4 hi, mid, lo;
+        split8(v0, v1, hi, mid, lo);
+        char* d = out3 + pix * (size_t)ld3 + (c8 >> 3) * 48;
+        *reinterpret_cast<u32x4*>(d) = hi;
+        *reinterpret_cast<u32x4*>(d + 16) = mid;
+        *reinterpret_cast<u32x4*>(d + 32) = lo;
+      }
+    }
   }
 }
 
@@ -122,14 +138,15 @@ __global__ __launch_bounds__(256) void stem_direct_kernel(const float* __restric
 
 bool opp_stem_direct_ok(int cout, int prec) { return cout == COUT && prec == OPP_PREC_BF16X3; }
 
-int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream) {
-  OPP_CHECK_ARG(img && wsplit && bias && out && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldc >= COUT, "stem_direct: bad argument");
+int opp_stem_direct(const float* img, int H, int W, const float* wsplit, const float* bias, float* out, int ldc, hipStream_t stream, void* out3, int ld3) {
+  OPP_CHECK_ARG(img && wsplit && bias && (out || out3) && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && ldc >= COUT, "stem_direct: bad argument");
   OPP_CHECK_ARG((reinterpret_cast<uintptr_t>(wsplit) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && ldc % 4 == 0,
                 "stem_direct: weights / output must be 16-byte aligned, ldc a multiple of 4");
+  OPP_CHECK_ARG(out3 == nullptr || ((reinterpret_cast<uintptr_t>(out3) & 15) == 0 && ld3 % 16 == 0 && ld3 >= COUT * 6), "stem_direct: bad split output");
   const int Ho = H / 2, Wo = W / 2;
   OPP_CHECK_ARG((size_t)Ho * Wo * ldc < (1ull << 31), "stem_direct: output too large for 32-bit indexing");
   hipLaunchKernelGGL(stem_direct_kernel, dim3(opp_cdiv(Wo, TX), opp_cdiv(Ho, TY)), dim3(256), 0, stream, img, H, W, Ho, Wo,
-                     reinterpret_cast<const char*>(wsplit), bias, out, ldc);
+                     reinterpret_cast<const char*>(wsplit), bias, out, ldc, static_cast<char*>(out3), ld3);
   OPP_CHECK_LAUNCH("stem_direct_kernel");
   return OPP_OK;
 }

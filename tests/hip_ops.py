@@ -123,6 +123,48 @@ def conv2d(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0
     return from_nhwc(y, cout), (pad_part.abs().max().item() if pad_part.numel() else 0.0)
 
 
+def conv2d_split(x_nchw, w, scale=None, bias=None, stride=1, residual=None, res_mode=0, act=0, cfg=-1, give_fp32=True, give_split=True,
+                 want_fp32=True, want_split=True):
+    """The bf16x3 convolution through opp_conv2d_nhwc_split: input as fp32 rows and / or pre-split rows (opp_pack_b3 of the fp32 rows), output
+    as fp32 rows and / or pre-split rows.  -> (y fp32 NHWC padded or None, y_split raw floats or None, the plain opp_conv2d_nhwc(prec=2) result,
+    opp_pack_b3 of that result)"""
+    lib = _lib.load()
+    cout, cin, ks, _ = w.shape
+    cin_p, cout_p = pad32(cin), pad32(cout)
+    x = to_nhwc_padded(x_nchw, cin_p)
+    H, W = x_nchw.shape[2:]
+    pad = ks // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    wp = torch.empty(cout_p * lib.opp_conv_packed_k(cin, ks), device="cuda")
+    wd = w.cuda().contiguous()
+    sd = None
+    if scale is not None:
+        sd = torch.zeros(cout_p, device="cuda")
+        sd[:cout] = scale.cuda()
+    _lib.check(lib.opp_pack_conv_weight(wd.data_ptr(), sd.data_ptr() if sd is not None else None, cout, cin, ks,
+                                        cout_p, cin_p, wp.data_ptr(), _s()), "pack")
+    wp = pack_b3(wp)
+    bd = None
+    if bias is not None:
+        bd = torch.zeros(cout_p, device="cuda")
+        bd[:cout] = bias.cuda()
+    rd = to_nhwc_padded(residual, cout_p) if residual is not None else None
+    ref = torch.full((Ho, Wo, cout_p), float("nan"), device="cuda")
+    _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, wp.data_ptr(), bd.data_ptr() if bd is not None else None,
+                                   cout_p, ks, stride, rd.data_ptr() if rd is not None else None, res_mode, act,
+                                   ref.data_ptr(), cfg, 2, None, _s()), "conv2d")
+    xs = pack_b3(x)
+    y = torch.full((Ho, Wo, cout_p), float("nan"), device="cuda") if want_fp32 else None
+    ys = torch.full((Ho * Wo * cout_p // 2 * 3,), float("nan"), device="cuda") if want_split else None
+    _lib.check(lib.opp_conv2d_nhwc_split(x.data_ptr() if give_fp32 else None, xs.data_ptr() if give_split else None, H, W, cin, wp.data_ptr(),
+                                         bd.data_ptr() if bd is not None else None, cout_p, ks, stride,
+                                         rd.data_ptr() if rd is not None else None, res_mode, act,
+                                         y.data_ptr() if y is not None else None, ys.data_ptr() if ys is not None else None, cfg, _s()),
+               "conv2d_split")
+    torch.cuda.synchronize()
+    return y, ys, ref, pack_b3(ref)
+
+
 def layer_norm(x, g, b, res=None):
     lib = _lib.load()
     x = x.cuda().contiguous()

@@ -236,6 +236,61 @@ def test_conv_bf16x3(cin, cout, ks, stride, H, W, cfg):
         ops.conv2d(x, w, scale, bias, stride, res, 1, 1, 3, h2=3)
 
 
+# pre-split activations (round 6): cin, cout, ks, stride, H, W, res_mode, act
+PRESPLIT_CASES = [
+    (128, 128, 3, 1, 40, 36, 1, 1),     # layer1: shortcut + ReLU
+    (128, 196, 3, 2, 40, 36, 0, 1),     # layer2.0.conv1, stride 2, 224 stored columns
+    (128, 196, 1, 2, 40, 36, 0, 0),     # layer2.0.downsample
+    (196, 256, 1, 2, 24, 20, 0, 0),     # layer3.0.downsample: 1 x 1 over 196 (224 stored) channels -- no packed K tail
+    (196, 256, 1, 1, 24, 20, 2, 0),     # layer2_outconv + bilinear x2 residual
+    (256, 256, 3, 1, 16, 16, 1, 1),     # layer3 (few tiles under a long K: runs as K slices + the fixed-order epilogue)
+    (256, 196, 3, 1, 24, 20, 0, 2),     # layer2_outconv2[3], LeakyReLU upstream
+    (64, 32, 3, 1, 9, 7, 0, 0),         # two channel groups, ragged tile
+    (32, 64, 1, 1, 5, 3, 0, 0),         # a single chunk
+]
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W,res_mode,act", PRESPLIT_CASES)
+@pytest.mark.parametrize("cfg", [-1, 2, 20, 22, 25, 26])
+def test_conv_presplit_is_bit_identical(cin, cout, ks, stride, H, W, res_mode, act, cfg):
+    """opp_conv2d_nhwc_split (input read as the bf16 triples its producer wrote, output written as triples) against opp_conv2d_nhwc(prec=2),
+    which splits the same fp32 values in its K loop: the same bits in, the same MFMA sequence -> the same bits out, on every tile; the
+    pre-split output rows are exactly opp_pack_b3 of the fp32 rows."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(cin * 7 + cout + ks + stride + H)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, ks, ks, generator=g) * (2.0 / (cin * ks * ks)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
+    res = None
+    if res_mode == 1:
+        res = torch.randn(1, cout, Ho, Wo, generator=g)
+    elif res_mode == 2:
+        res = torch.randn(1, cout, Ho // 2, Wo // 2, generator=g)
+    y, ys, ref, ref_s = ops.conv2d_split(x, w, scale, bias, stride, res, res_mode, act, cfg, give_fp32=False)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(y, ref)
+    assert torch.equal(ys.view(torch.int32), ref_s.view(torch.int32))
+    # the split rows alone (no fp32 copy of the output), input offered both ways
+    y2, ys2, _, _ = ops.conv2d_split(x, w, scale, bias, stride, res, res_mode, act, cfg, want_fp32=False)
+    assert y2 is None and torch.equal(ys2.view(torch.int32), ref_s.view(torch.int32))
+
+
+@pytest.mark.parametrize("cfg", [-1, 22, 25])
+def test_conv_presplit_falls_back_to_fp32_rows_for_a_packed_k_tail(cfg):
+    """3 x 3 over 196 channels packs its last 4 channels 8 taps to a chunk: that K walk reads the fp32 rows; the split OUTPUT is still written.
+    Without the fp32 rows the call is refused."""
+    from tests import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 196, 20, 24, generator=g)
+    w = torch.randn(196, 196, 3, 3, generator=g) * 0.03
+    y, ys, ref, ref_s = ops.conv2d_split(x, w, None, None, 1, None, 0, 1, cfg)
+    assert torch.equal(y, ref) and torch.equal(ys.view(torch.int32), ref_s.view(torch.int32))
+    with pytest.raises(Exception):
+        ops.conv2d_split(x, w, None, None, 1, None, 0, 1, cfg, give_fp32=False)
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(196, 256, 12, 16), (128, 196, 20, 12)])
 def test_conv1x1_bilinear_residual(cin, cout, H, W):
     """lateral 1x1 conv + align_corners=True x2 upsample of the coarser map (resnet.py:151-157)."""
@@ -278,6 +333,8 @@ def test_layernorm(C):
 def test_linear_layernorm_fused(M, K, N, h2, with_res):
     """GEMM with the LayerNorm (+ residual) of LoFTREncoderLayer fused into its epilogue vs fp64."""
     from tests import hip_ops as ops
+    if h2 == 1:
+        _needs_fp16x2()
     g = torch.Generator().manual_seed(M + K + N + h2)
     A = torch.randn(M, K, generator=g)
     W = torch.randn(N, K, generator=g) * (1.0 / K) ** 0.5

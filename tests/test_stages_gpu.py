@@ -69,6 +69,27 @@ def test_direct_stem_is_bit_identical_to_im2col_gemm(hw):
     assert torch.equal(fc, rc) and torch.equal(ff, rf)
 
 
+@pytest.mark.parametrize("hw", [(8, 8), (40, 72), (128, 128), (512, 512)])
+def test_presplit_activation_chain_is_bit_identical(hw):
+    """Round 6: the bf16x3 backbone can hand its maps from layer to layer as pre-split bf16 triples (written once by the producing epilogue, read by
+    every convolution whose K walk has no packed tail; csrc/api.hip backbone_impl, gemm_mfma.hip ASP) instead of splitting fp32 rows in every K
+    loop -- with OPP_ASP=1 (opt-in: measured slower overall).  Same triples, same product order -> both feature maps agree bit for
+    bit with the default fp32-row chain (K slices of the 1/8-resolution layers and the bilinear laterals included)."""
+    import os
+    from tests import hip_ops as ops
+    cfg, sd, _ = H.e2e_setup("e2e_128x128_n300_thr0")
+    model = ops.make_model(cfg, sd, "bf16x3")
+    img = torch.rand(1, 1, hw[0], hw[1], generator=torch.Generator().manual_seed(3 * hw[0] + hw[1]))
+    rc, rf = ops.backbone(model, img)
+    os.environ["OPP_ASP"] = "1"
+    try:
+        fc, ff = ops.backbone(model, img)
+    finally:
+        del os.environ["OPP_ASP"]
+    assert torch.isfinite(fc).all() and torch.isfinite(ff).all()
+    assert torch.equal(fc, rc) and torch.equal(ff, rf)
+
+
 def test_tokens_and_transformer(small):
     from oracle import onepose_oracle as O
     from tests import hip_ops as ops

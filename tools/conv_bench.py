@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--cfgs", default=None, help="comma list: only these tile configs")
     ap.add_argument("--prec", type=int, default=2, help="operand arithmetic: 0 fp32, 1 fp16x2, 2 bf16x3 (default)")
+    ap.add_argument("--split", type=int, default=0, help="bf16x3 convolutions through opp_conv2d_nhwc_split: 1 = pre-split input, fp32 output; "
+                    "2 = pre-split input and output (no fp32 copy); 3 = pre-split input, both outputs")
     args = ap.parse_args()
     lib = _lib.load()
     s = torch.cuda.current_stream().cuda_stream
@@ -105,6 +107,17 @@ def main():
             def fn():
                 _lib.check(lib.opp_conv2d_nhwc(x.data_ptr(), H, W, cin, w.data_ptr(), bias.data_ptr(), cop, ks, stride,
                                                None, 0, 1, y.data_ptr(), cfg, args.prec, None, s), "conv")
+            if args.split:
+                if args.prec != 2 or (ks == 3 and cin % 32 != 0):
+                    continue
+                xs = torch.empty(x.numel() // 2 * 3, device="cuda")
+                _lib.check(lib.opp_pack_b3(x.data_ptr(), xs.data_ptr(), x.numel(), s), "pack_b3")
+                ys = torch.empty(y.numel() // 2 * 3, device="cuda")
+
+                def fn():   # noqa: F811
+                    _lib.check(lib.opp_conv2d_nhwc_split(None, xs.data_ptr(), H, W, cin, w.data_ptr(), bias.data_ptr(), cop, ks, stride, None, 0, 1,
+                                                         y.data_ptr() if args.split != 2 else None, ys.data_ptr() if args.split >= 2 else None, cfg, s),
+                               "conv_split")
             try:
                 us = timeit(fn, args.iters)
                 print("%-32s cfg%d  %8.1f us  alg %6.1f TF  padded %6.1f TF" % (name, cfg, us, alg / us / 1e6, padf / us / 1e6), flush=True)
