@@ -81,8 +81,10 @@ __device__ __forceinline__ void opp_store_split4(void* base, size_t row_bytes_of
 // producing layer's epilogue), is loaded in 16-byte pieces exactly like the weight rows and goes to LDS with one ds_write_b128 per piece --
 // no split arithmetic in the K loop (it was redone for every tap of a 3 x 3 window and every column tile: ~120 of the ~190 VALU instructions
 // per 32-k chunk and wave, profiles/r06_pmc_conv_*.txt) and no 8-byte LDS stores (a quarter of the LDS cycles were their bank conflicts).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_FP32, bool ASP = false>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
+// (The body is a device function with two kernel entries -- opp_gemm_kernel<..., PREC> and opp_gemm_asp_kernel<..., PREC> -- so that the
+// symbol names of the default kernels, which every profile under profiles/ is keyed by, do not change with the opt-in variant.)
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL, int DEPTH, int PREC, bool ASP>
+__device__ __forceinline__ void opp_gemm_body(const OppGemm& g) {
   constexpr bool H2 = PREC == OPP_PREC_FP16X2;   // operands as hi+lo fp16 pairs, 3 fp16 MFMA products
   constexpr bool H3 = PREC == OPP_PREC_BF16X3;   // operands as hi+mid+lo bf16 triples (exact), 6 bf16 MFMA products
   constexpr int kLdsStride = lds_stride(PREC);
@@ -1205,6 +1207,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const O
   }
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool CONV, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_FP32>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_kernel(const OppGemm g) {
+  opp_gemm_body<BM, BN, WAVES_M, WAVES_N, CONV, ABL, DEPTH, PREC, false>(g);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int ABL = 0, int DEPTH = 2, int PREC = OPP_PREC_BF16X3>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void opp_gemm_asp_kernel(const OppGemm g) {
+  opp_gemm_body<BM, BN, WAVES_M, WAVES_N, true, ABL, DEPTH, PREC, true>(g);
+}
+
 // out = act(sum_s part[s] + bias + R): the split-K slices of a convolution summed in slice order (deterministic), then the epilogue
 // the unsplit kernel fuses (folded-BN bias, same-shape residual, ReLU / LeakyReLU); float4 granularity over [M][ld]
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float4* __restrict__ part, int splits, size_t stride4, size_t n4, int ld4,
@@ -1276,7 +1287,7 @@ int launch_prec(const OppGemm& g, hipStream_t stream, size_t extra_lds) {
     constexpr bool kAspBuilt = PREC == OPP_PREC_BF16X3 && DEPTH == 2 && !kNarrowB3 && (NT == 512 || (BM == 64 && BN == 64));
     if (g.conv && g.a_split) {
       if constexpr (kAspBuilt) {
-        auto k = opp_gemm_kernel<BM, BN, WAVES_M, WAVES_N, true, 0, DEPTH, PREC, true>;
+        auto k = opp_gemm_asp_kernel<BM, BN, WAVES_M, WAVES_N, 0, DEPTH, PREC>;
         static OppLdsOnce attr_done;
         set_lds_once(k, lds, attr_done);
         hipLaunchKernelGGL(k, dim3(tiles, g.k_splits > 1 ? g.k_splits : 1), dim3(NT), lds, stream, g);
@@ -1334,7 +1345,9 @@ int launch_timed(const OppGemm& g_in, hipStream_t stream) {   // conv kernel wit
     return OPP_ERR_INVALID;
   }
   const size_t lds = (size_t)2 * (BM + BN) * lds_stride(PREC) * sizeof(float);
-  auto k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, PREC, ASP>;
+  void (*k)(const OppGemm) = nullptr;
+  if constexpr (ASP) k = opp_gemm_asp_kernel<BM, BN, WM, WN, ABL, 2, PREC>;
+  else k = opp_gemm_kernel<BM, BN, WM, WN, true, ABL, 2, PREC>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(opp_cdiv(g.M, BM) * opp_cdiv(g.n_store, BN)), dim3(WM * WN * 64), lds, stream, g);
   OPP_CHECK_LAUNCH("opp_gemm_kernel(timed)");
