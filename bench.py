@@ -87,7 +87,8 @@ MFMA_SYMBOLS = [
     (1009, "enc_layer64_kernel", "one encoder layer behind the QKV projection in ONE launch: attention apply, merge, norm1, mlp.0, ReLU, "
                                  "mlp.2, norm2, residual on 64-token tiles held in LDS (enc_chain_kernel on 32-token tiles when "
                                  "encoder_fusion = 1); 2 x T x (7 C^2 + 32 C) FLOP"),
-    (1012, "gemm_ss_kernel<3>", "coarse score GEMM on operands pre-split once, LDS-DMA staged, + dual-softmax statistics + score matrix"),
+    (1012, "gemm_ss_kernel<3>", "coarse score GEMM on operands pre-split once, LDS-DMA staged, + dual-softmax statistics + score matrix "
+                                "(gemm_ss_res3_kernel in the kernel trace since r06: three resident workgroups per CU)"),
     (1010, "gemm_ss_kernel<1>", "coarse score GEMM sweep 1 (statistics only; two-sweep matcher)"),
     (1011, "gemm_ss_kernel<2>", "coarse score GEMM sweep 2 (confidences written once; two-sweep matcher)"),
     (1014, "opp_gemm_kernel<128, 128, 4, 2, true> x 4 K slices", "3x3 convolutions of the 1/8-resolution stage (4096 pixels, K = 1792 .. 2304) as "

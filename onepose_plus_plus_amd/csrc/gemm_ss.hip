@@ -887,6 +887,291 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_persist_kernel(const OppGemmSS 
   }
 }
 
+// ---- three residents per CU (r06): statistics + score matrix, OPP_SS_STATS_STORE ---------------------------------------------------
+// The timeline of the one-tile kernel (profiles/r06_ss_timeline.txt) says a tile is 12.3 k cycles of MFMAs inside 43 k: 6.3 k of prologue
+// latency, 12.4 k of epilogue, and a K loop that runs at half rate whenever the CU's other resident is in its own.  Staggering, static tile
+// lists and wave priorities did not change that; what does is a THIRD resident: with three workgroups per CU one of them is in its K loop far
+// more often, and the critical path of a CU's five tiles is two tiles long instead of three.  What it costs: LDS for TWO k16-stages instead of
+// three (2 x 24 KB + 4 KB of statistics scratch = 52 KB, three workgroups = 156 KB) and <= 168 registers:
+//   * ONE operand fragment set, read right behind the stage barrier (the other residents' MFMAs run under that LDS latency);
+//   * ONE stage of LDS-DMA in flight: stage s + 1 goes into the slot stage s - 1 was read from, issued one piece per four MFMAs of stage s
+//     (every wave read its stage s - 1 fragments before the barrier that opens stage s), and is awaited with vmcnt(0) at the next barrier;
+//   * the epilogue of the persistent kernel: the tile staged through LDS in two halves of 64 columns (33 KB), row statistics merged online.
+// Same tile, same accumulation sequence: the score tiles are bit-identical to gemm_ss_kernel's; the row statistics are the persistent kernel's
+// (a function of the row's values only).
+constexpr int R3_NS = 2;
+constexpr size_t R3_LDS = (size_t)R3_NS * SLOT + 4096;
+static_assert(PT_HC * PT_TS * 4 <= R3_NS * SLOT, "a staged half tile must fit the two operand slots");
+
+__global__ __launch_bounds__(NT, 3) void gemm_ss_res3_kernel(const OppGemmSS g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef OPP_TUNING
+  const unsigned long long ts0 = __builtin_readcyclecounter();
+  unsigned long long ts1 = 0, ts2 = 0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  // one tile per workgroup, the XCD-aware strip order of gemm_ss_kernel.  (Static tile lists -- 2 + 2 + 1 tiles per CU on 768 resident workgroups
+  // -- were measured as well: a tile costs 60 k cycles with three residents, the two-tile critical path is as long as before, matcher 143 vs 143 us;
+  // the dynamic grid lets whichever workgroup slot frees first take the next tile: -4 us, profiles/r06_ss_res3_ab.txt.)
+  int tile_lin = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tile_lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int RS = 8;
+  const int strip = tile_lin / (RS * tiles_n);
+  const int within = tile_lin - strip * (RS * tiles_n);
+  const int strip_rows = min(RS, tiles_m - strip * RS);
+  const int tile_n = within / strip_rows;
+  const int tile_m = strip * RS + (within - tile_n * strip_rows);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  unsigned a_voff[A_LD], b_voff[B_LD];
+#pragma unroll
+  for (int i = 0; i < A_LD; ++i) {
+    const int P = (wave * A_LD + i) * 64 + lane;
+    const int row = P / 6, pos = P - row * 6;
+    const int q = (pos + 3 * ((row >> 3) & 1)) % 6;
+    a_voff[i] = m0 + row < g.M ? (unsigned)(row * g.lda + q * 16) : kOob;
+  }
+#pragma unroll
+  for (int i = 0; i < B_LD; ++i) {
+    const int P = (wave * B_LD + i) * 64 + lane;
+    const int row = P / 6, pos = P - row * 6;
+    const int q = (pos + 3 * ((row >> 3) & 1)) % 6;
+    b_voff[i] = n0 + row < g.N ? (unsigned)(row * g.ldb + q * 16) : kOob;
+  }
+  const int soffA0 = m0 * g.lda, soffB0 = n0 * g.ldb;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto dma_item = [&](int s, int k, bool live) {
+    char* base = smem + (s & 1) * SLOT;
+    if (k < A_LD) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, live ? g.a_bytes : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + (wave * A_LD + k) * 1024), 16, (int)a_voff[k], soffA0 + s * ROWB, 0, 0);
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), 0, live ? g.b_bytes : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(base + A_BYTES + (wave * B_LD + (k - A_LD)) * 1024), 16, (int)b_voff[k - A_LD],
+                                               soffB0 + s * ROWB, 0, 0);
+    }
+  };
+  int foff[3];
+  {
+    const int b3 = (l31 >> 3) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) foff[p] = 16 * ((3 * half + p + 3 * b3) % 6);
+  }
+  const int a_row = (wm * TM * 32 + l31) * ROWB;
+  const int b_row = A_BYTES + (wn * TN * 32 + l31) * ROWB;
+  u32x4 fa[TM][3], fb[TN][3];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ns = g.K / 16;
+
+  // one stage: my pieces of stage s landed (vmcnt(0): nothing else is in flight) -> barrier (stage s is complete and visible, and every wave has
+  // read its fragments of stage s - 1) -> fragments of stage s -> 24 MFMAs with the six pieces of stage s + 1 behind them
+  auto stage = [&](int s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char* base = smem + (s & 1) * SLOT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i][p] = *reinterpret_cast<const u32x4*>(base + a_row + i * 32 * ROWB + foff[p]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j][p] = *reinterpret_cast<const u32x4*>(base + b_row + j * 32 * ROWB + foff[p]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool live = s + 1 < ns;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+    int n = 0;
+#pragma unroll
+    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[pr]]), __builtin_bit_cast(bf16x8, fb[j][PB[pr]]),
+                                                               acc[i][j], 0, 0, 0);
+          if (n % 4 == 3 && n / 4 < LPS) {
+            dma_item(s + 1, n / 4, live);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          ++n;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#pragma unroll
+  for (int k = 0; k < LPS; ++k) dma_item(0, k, true);
+#ifdef OPP_TUNING
+  ts1 = __builtin_readcyclecounter();
+#endif
+  for (int s = 0; s < ns; ++s) stage(s);
+#ifdef OPP_TUNING
+  ts2 = __builtin_readcyclecounter();
+#endif
+
+  // ---- epilogue (gemm_ss_persist_kernel's, without the next tile) --------------------------------------------------------------------
+  // (thread coordinates re-derived from an opaque copy of the thread index: hoisted out of the tile loop, the epilogue's address arithmetic
+  // stays live across the K loop and spills)
+  int te = tid;
+  asm volatile("" : "+v"(te));
+  const int e_wave = __builtin_amdgcn_readfirstlane(te >> 6);
+  const int e_wm = e_wave / WN, e_wn = e_wave % WN, e_half = (te >> 5) & 1, e_l31 = te & 31;
+  const int e_rrow = te & (BM - 1), e_rsub = te >> 7;
+  if ((g.out_mul != 1.f) || (g.out_div != 1.f)) {
+    const float rd = 1.0f / g.out_div;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = div_invariant(acc[i][j][r] * g.out_mul, g.out_div, rd);
+  }
+  auto row_of = [&](int i, int r) { return e_wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * e_half; };
+  if (g.row_mask != nullptr) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float mk = g.row_mask[min(m0 + row_of(i, r), g.M - 1)];
+        const float add = mk == 0.f ? -1e9f : 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j][r] += add;
+      }
+  }
+  const int nrows = min(BM, g.M - m0), ncols = min(BN, g.N - n0);
+  const bool full = nrows == BM && ncols == BN;
+  float* T = reinterpret_cast<float*>(smem);                                  // [PT_HC][PT_TS] over the two (dead) operand slots
+  float* red_cmax = reinterpret_cast<float*>(smem + R3_NS * SLOT);            // [WM][BN]
+  float* red_csum = red_cmax + WM * BN;                                       // [WM][BN]
+  float* red_rm = red_csum + WM * BN;                                         // [2][BM]
+  float* red_rs = red_rm + 2 * BM;                                            // [2][BM]
+  auto vmax = [](float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  };
+  constexpr int CPS = PT_HC / 2;
+  auto body = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    float cmx[TN], csm[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = vmax(m, (FULL || row_of(i, r) < nrows) ? acc[i][j][r] : -INFINITY);
+      m = vmax(m, __shfl_xor(m, 32, 64));
+      if (e_half == 0) red_cmax[e_wm * BN + e_wn * TN * 32 + j * 32 + e_l31] = m;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               // the zero-sized tail DMAs and the last fragment reads
+    __syncthreads();                                                           // both slots are dead; the column maxima are visible
+#pragma unroll
+    for (int j = 0; j < TN; ++j) cmx[j] = vmax(red_cmax[e_wn * TN * 32 + j * 32 + e_l31], red_cmax[BN + e_wn * TN * 32 + j * 32 + e_l31]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += (FULL || row_of(i, r) < nrows) ? __expf(acc[i][j][r] - cmx[j]) : 0.f;
+      csm[j] = sm + __shfl_xor(sm, 32, 64);
+      if (e_half == 0) red_csum[e_wm * BN + e_wn * TN * 32 + j * 32 + e_l31] = csm[j];
+    }
+    if (e_wm == 0 && e_half == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        if (e_wn * TN * 32 + j * 32 + e_l31 < ncols) g.stat_colmax[(size_t)tile_m * g.N + n0 + e_wn * TN * 32 + j * 32 + e_l31] = cmx[j];
+    }
+    float RM = -INFINITY, RSUM = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (e_wn == h) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              const int col = j * 32 + e_l31, row = e_wm * TM * 32 + i * 32 + 8 * q4 + 4 * e_half;
+              *reinterpret_cast<float4*>(T + col * PT_TS + row) =
+                  make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]);
+            }
+      }
+      __syncthreads();
+      {
+        const int c0 = e_rsub * CPS;
+        float rv[CPS];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) {
+          rv[c] = T[(c0 + c) * PT_TS + e_rrow];
+          m = vmax(m, (FULL || h * PT_HC + c0 + c < ncols) ? rv[c] : -INFINITY);
+        }
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CPS; ++c) sacc += (FULL || h * PT_HC + c0 + c < ncols) ? __expf(rv[c] - m) : 0.f;
+        const float M2 = vmax(RM, m);
+        if (FULL || M2 > -INFINITY) RSUM = RSUM * __expf(RM - M2) + sacc * __expf(m - M2);
+        RM = M2;
+      }
+#pragma unroll
+      for (int it = 0; it < PT_HC * (BM / 4) / NT; ++it) {
+        const int u = te + it * NT;
+        const int col = u / (BM / 4), r4 = (u - col * (BM / 4)) * 4;
+        const int gc = h * PT_HC + col;
+        if (FULL || (gc < ncols && r4 + 3 < nrows)) {
+          *reinterpret_cast<float4*>(g.C + (size_t)(n0 + gc) * g.ldc + m0 + r4) = *reinterpret_cast<const float4*>(T + col * PT_TS + r4);
+        } else if (gc < ncols) {
+          for (int e = 0; e < 4; ++e)
+            if (r4 + e < nrows) g.C[(size_t)(n0 + gc) * g.ldc + m0 + r4 + e] = T[col * PT_TS + r4 + e];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();                                                         // the staged e_half is consumed
+    }
+    red_rm[e_rsub * BM + e_rrow] = RM;
+    red_rs[e_rsub * BM + e_rrow] = RSUM;
+    __syncthreads();
+    if (te < BM) {
+      if (te < nrows) {
+        const float ma = red_rm[te], mb = red_rm[BM + te];
+        const float M2 = vmax(ma, mb);
+        const size_t o = (size_t)(m0 + te) * tiles_n + tile_n;
+        g.stat_rowmax[o] = M2;
+        g.stat_rowsum[o] = red_rs[te] * __expf(ma - M2) + red_rs[BM + te] * __expf(mb - M2);
+      }
+    } else if (te - BM < ncols) {
+      const int u = te - BM;
+      g.stat_colsum[(size_t)tile_m * g.N + n0 + u] = red_csum[u] + red_csum[BN + u];
+    }
+  };
+  if (full) body(std::true_type{});
+  else body(std::false_type{});
+#ifdef OPP_TUNING
+  if (g.dbg_ts != nullptr && lane == 0) {
+    unsigned long long* o = g.dbg_ts + ((size_t)tile_lin * 4 + wave) * 4;
+    o[0] = ts0;
+    o[1] = ts1;
+    o[2] = ts2;
+    o[3] = __builtin_readcyclecounter();
+  }
+#endif
+}
+
 #ifdef OPP_TUNING
 unsigned long long* g_ss_dbg_ts = nullptr;
 int g_ss_dbg_mode = 0;
@@ -963,6 +1248,19 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
     static const int persist_env = getenv("OPP_SS_PERSIST") ? atoi(getenv("OPP_SS_PERSIST")) : 0;
     static const int delay_env = getenv("OPP_SS_DELAY") ? atoi(getenv("OPP_SS_DELAY")) : kPersistDelay;
     const int tiles = opp_cdiv(g.M, BM) * opp_cdiv(g.N, BN);
+    // default since r06: three resident workgroups per CU (gemm_ss_res3_kernel; OPP_SS_RES3=0 selects the two-resident one-tile kernel).  Measured
+    // (profiles/r06_ss_res3_ab.txt): matcher 138.3 -> 135.7 us, matrix pipe busy 0.383 -> 0.401 inside the forward, forward +0.6 % with one
+    // forward in flight, unchanged with four
+    static const int res3_env = getenv("OPP_SS_RES3") ? atoi(getenv("OPP_SS_RES3")) : 1;
+    if (res3_env && !persist_env && g.vec_store) {
+      auto k = gemm_ss_res3_kernel;
+      static OppLdsOnce lds_once;
+      opp_lds_opt_in(reinterpret_cast<const void*>(k), R3_LDS, lds_once);
+      OppProfScope prof(OPP_PROF_SCORE_SS, stream, 2.0 * (double)g.M * (double)g.N * (double)g.K);
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(NT), R3_LDS, stream, g);
+      OPP_CHECK_LAUNCH("gemm_ss_res3_kernel");
+      return OPP_OK;
+    }
     if (persist_env && tiles > 8 && g.vec_store) {
       const int slots = 2 * opp_cu_count();
       g.delay = tiles > slots ? delay_env : 0;         // (one tile per workgroup: nothing to de-phase)

@@ -78,7 +78,7 @@ def test_compact_line_fits_the_driver_tail(path):
 def test_compact_line_sheds_before_it_overflows():
     sys.path.insert(0, ROOT)
     import bench
-    with open(_full_lines()[-1]) as f:
+    with open([p for p in _full_lines() if "rank_devices" in json.load(open(p))["config"]][-1]) as f:      # the newest FULL record (sidecar)
         full = json.load(f)
     full["config"]["rank_devices"] = [dict(full["config"]["rank_devices"][0], rank=i, local_rank=i, device=i) for i in range(8)]
     line = json.dumps(bench.compact_line(full, "bench_detail.json", limit=2000))

@@ -12,7 +12,7 @@ util = list(csv.DictReader(open(sys.argv[3]))) if len(sys.argv) > 3 else []
 def trace_avg(sym):
     key = ("opp_gemm_kernel<%s>" % sym) if sym[0].isdigit() else sym.split("<")[0]
     for n, r in stats.items():
-        if key in n and ("gemm_ss" not in key or sym[-2] in n):
+        if (key in n and ("gemm_ss" not in key or sym[-2] in n)) or (sym == "gemm_ss_kernel<3>" and "gemm_ss_res3_kernel" in n):
             return float(r["AverageNs"]) / 1e3, int(r["Calls"])
     return None, 0
 
@@ -21,7 +21,8 @@ def mfma_util(sym):
     key = ("opp_gemm_kernel<%s>" % sym) if sym[0].isdigit() else sym.split("<")[0]
     best = None
     for r in util:
-        if key in r["Kernel"] and (best is None or int(r["Launches"]) > int(best["Launches"])):
+        if (key in r["Kernel"] or (sym == "gemm_ss_kernel<3>" and "gemm_ss_res3_kernel" in r["Kernel"])) and \
+                (best is None or int(r["Launches"]) > int(best["Launches"])):
             best = r
     return best["MFMAPipeUtilisation"] if best else "-"
 

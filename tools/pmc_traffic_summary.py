@@ -42,6 +42,8 @@ def main(d, out):
     for k, n, fb, wb, wg in rows:
         if "opp_gemm_kernel<" in k:
             t = k[k.find("<") + 1:k.find(">")]
+        elif "gemm_ss_res3_kernel" in k:      # the default single-sweep score GEMM since r06: profile symbol gemm_ss_kernel<3> (bench.py MFMA_SYMBOLS)
+            t = "gemm_ss_kernel<3>"
         elif "gemm_ss_kernel<" in k:
             t = "gemm_ss_kernel<%s>" % k[k.find("<") + 1:k.find(">")]
         else:
