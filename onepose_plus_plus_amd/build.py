@@ -74,6 +74,11 @@ def build(force=False, verbose=True, tuning=False, variant=None):
         extra.pop("gemm_mfma.hip", None)
     if variant == "noslp_all":
         flags = flags + ["-fno-slp-vectorize"]
+    if variant and variant.startswith("def:"):          # tools: one extra macro definition, e.g. --variant def:R3_DMA_EVERY=2
+        flags = flags + ["-D" + variant[4:]]
+        suffix = "_" + variant[4:].replace("=", "").lower()
+        obj_dir = OBJ + suffix
+        lib_path = LIB.replace(".so", suffix + ".so")
     return _build(force, verbose, obj_dir, lib_path, flags, extra)
 
 

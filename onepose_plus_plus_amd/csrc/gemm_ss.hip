@@ -900,6 +900,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_persist_kernel(const OppGemmSS 
 // Same tile, same accumulation sequence: the score tiles are bit-identical to gemm_ss_kernel's; the row statistics are the persistent kernel's
 // (a function of the row's values only).
 constexpr int R3_NS = 2;
+#ifndef R3_DMA_EVERY
+#define R3_DMA_EVERY 4         // one DMA piece behind every R3_DMA_EVERY-th MFMA of a stage (6 pieces, 24 MFMAs); 1 / 2 / 3 measured the same (134-138 us)
+#endif
 constexpr size_t R3_LDS = (size_t)R3_NS * SLOT + 4096;
 static_assert(PT_HC * PT_TS * 4 <= R3_NS * SLOT, "a staged half tile must fit the two operand slots");
 
@@ -1003,8 +1006,8 @@ __global__ __launch_bounds__(NT, 3) void gemm_ss_res3_kernel(const OppGemmSS g) 
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[pr]]), __builtin_bit_cast(bf16x8, fb[j][PB[pr]]),
                                                                acc[i][j], 0, 0, 0);
-          if (n % 4 == 3 && n / 4 < LPS) {
-            dma_item(s + 1, n / 4, live);
+          if (n % R3_DMA_EVERY == R3_DMA_EVERY - 1 && n / R3_DMA_EVERY < LPS) {
+            dma_item(s + 1, n / R3_DMA_EVERY, live);
             __builtin_amdgcn_sched_barrier(0);
           }
           ++n;
@@ -1251,7 +1254,8 @@ int opp_gemm_ss(const OppGemmSS& g_in, hipStream_t stream) {
     // default since r06: three resident workgroups per CU (gemm_ss_res3_kernel; OPP_SS_RES3=0 selects the two-resident one-tile kernel).  Measured
     // (profiles/r06_ss_res3_ab.txt): matcher 138.3 -> 135.7 us, matrix pipe busy 0.383 -> 0.401 inside the forward, forward +0.6 % with one
     // forward in flight, unchanged with four
-    static const int res3_env = getenv("OPP_SS_RES3") ? atoi(getenv("OPP_SS_RES3")) : 1;
+    const char* res3_s = getenv("OPP_SS_RES3");            // (read per call: the tests switch it inside one process)
+    const int res3_env = res3_s ? atoi(res3_s) : 1;
     if (res3_env && !persist_env && g.vec_store) {
       auto k = gemm_ss_res3_kernel;
       static OppLdsOnce lds_once;

@@ -124,6 +124,29 @@ def test_matcher_vs_golden(small, name):
     assert (c >= 0).all() and c.sum(1).max() <= 1 + 1e-4 and c.sum(0).max() <= 1 + 1e-4
 
 
+@pytest.mark.parametrize("name", list(MATCHER_CASES))
+def test_three_resident_score_gemm_against_the_two_resident_kernel(name):
+    """Round 6: the single-sweep score GEMM runs three workgroups per CU on two LDS stages (gemm_ss_res3_kernel); OPP_SS_RES3=0 selects the
+    two-resident kernel on three stages.  Same tile, same accumulation sequence: the SCORE tiles are bit-identical, so the column statistics are;
+    the row statistics are merged online over two 64-column halves instead of two parts against a common maximum, i.e. they agree to rounding --
+    match indices identical, confidences within 1e-6 of each other (both within the golden bar, test_matcher_vs_golden)."""
+    import os
+    from tests import hip_ops as ops
+    from onepose_plus_plus_amd.synthetic import make_state_dict
+    cfg, f3d, f2d, data = H.matcher_setup(name)
+    model0 = ops.make_model(cfg, make_state_dict(cfg, 0), "bf16x3")
+    args = (model0, f3d[0], f2d[0], tuple(data["q_hw_c"]), data["keypoints3d"][0], 8.0, data["query_image_scale"][0])
+    got = ops.coarse_match(*args)
+    os.environ["OPP_SS_RES3"] = "0"
+    try:
+        ref = ops.coarse_match(*args)
+    finally:
+        del os.environ["OPP_SS_RES3"]
+    assert torch.equal(got["i_ids"], ref["i_ids"]) and torch.equal(got["j_ids"], ref["j_ids"])
+    assert (got["conf_matrix"] - ref["conf_matrix"]).abs().max() <= 1e-6
+    assert (got["mconf"] - ref["mconf"]).abs().max() <= 1e-6
+
+
 @pytest.mark.parametrize("name", list(FINE_CASES))
 def test_fine_vs_golden(small, name):
     from tests import hip_ops as ops
