@@ -1533,7 +1533,6 @@ int opp_gemm_launch_cfg(const OppGemm& g_in, int cfg, hipStream_t stream) {
     static const int prio_env = getenv("OPP_WAVE_PRIO") ? atoi(getenv("OPP_WAVE_PRIO")) : 0;
     if (prio_env) g.xcd_swizzle |= 2;
   }
-  const bool split = g.prec != OPP_PREC_FP32;
   OPP_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0 && g.K % 32 == 0, "gemm: bad M/N/K (%d,%d,%d)", g.M, g.N, g.K);
   OPP_CHECK_ARG(g.n_store >= g.N && (g.C || g.C3) && g.W && g.A0, "gemm: bad output/operands");
   OPP_CHECK_ARG((size_t)g.M * (size_t)g.ldc < (1ull << 31), "gemm: output too large for 32-bit indexing");

@@ -690,7 +690,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_ss_persist_kernel(const OppGemmSS 
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
   };
-  const int rrow = tid & (BM - 1), rsub = tid >> 7;                           // row pass: thread = (row, 32 of the half's 64 columns)
   constexpr int CPS = PT_HC / 2;
 
   // prologue of the first tile: three stages in flight
