@@ -35,6 +35,7 @@ DENSE = [
     ("dense 65536x1152x128", 65536, 1152, 128, [0, 20, 25]),
     ("dense 65536x128x128", 65536, 128, 128, [0]),
     ("qkv 9096x256x768", 9096, 256, 768, [0, 1, 20, 22, 25, 28]),
+    ("qkv0 4096x256x768", 4096, 256, 768, [2, 20, 22, 25, 26]),          # layer 0's projection of the image stream alone (object prefix cached)
     ("merge 9096x256x256", 9096, 256, 256, [1, 2, 0, 25, 26]),
     ("mlp1 9096x512x512", 9096, 512, 512, [0, 1, 25, 26]),
     ("mlp2 9096x512x256", 9096, 512, 256, [1, 2, 0, 25, 26]),
