@@ -12,7 +12,9 @@
 //                        (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi): not narrower than fp32, 2.65x the fp32 MFMA rate;
 //                        weights pre-split at pack time (48 B per 8 k), activations split on their way to LDS;
 //      fp32              v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain (157 TFLOP/s);
-//      fp16x2            opt-in, narrower than fp32: hi + lo fp16 pairs, three fp16 MFMAs per product.
+//      fp16x2            narrower than fp32 (hi + lo fp16 pairs, three fp16 MFMAs per product): instantiated in the tuning library only (r06).
+//    bf16x3 convolutions can also read their activations PRE-SPLIT (opp_gemm_asp_kernel, r06: the producing epilogue writes the triples once;
+//    opt-in OPP_ASP=1, measured no faster end to end).
 //  * Both operands are K-contiguous ("TN").  A 32-wide K chunk of a tile row is one 128 B line of fp32 activations
 //    (192 B of pre-split weights): a wave loads 8 rows per instruction with raw buffer loads (out-of-range lanes -- the
 //    padding halo of a convolution, rows past M -- read zeros from the buffer unit, so the K loop has no exec-masked control
